@@ -1,0 +1,149 @@
+/* arcvae_hip.h -- C ABI of libarcvae_hip.so: the MI355X (gfx950) kernels behind the SELFIES
+ * AR-CVAE training path of Raiden-Makoto/MLX-VAE.
+ *
+ * The reference has no FFI boundary of its own (its only boundary is the
+ * Python module API on top of the third-party `mlx` runtime), so this header IS the kernel
+ * boundary a maintainer would bind: each entry point replaces the MLX graph that one reference
+ * function builds, named in the comment above it (file:line under the reference tree).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, negative on error (ARCVAE_ERR_*); no exceptions cross the ABI;
+ *   - no allocation, no ownership transfer: every buffer is caller-owned DEVICE memory,
+ *     contiguous row-major float32 unless stated, parameter tensors 16-byte aligned;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); safe under hipGraph capture
+ *     (no sync, no malloc); re-entrant (no global mutable state);
+ *   - `const float* const*` arguments are HOST arrays of device pointers (one per LSTM layer);
+ *   - gradients are accumulated ("+="): zero the flat gradient buffer once per step;
+ *   - float32 arithmetic throughout (the reference's dtype), contractions on the exact-f32
+ *     MFMA forms; hidden_dim must be a multiple of 64, num_layers <= 8, num_conditions <= 8,
+ *     vocab_size <= 127.
+ */
+#ifndef ARCVAE_HIP_H
+#define ARCVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARCVAE_OK 0
+#define ARCVAE_ERR_ARG (-1)
+#define ARCVAE_ERR_LAUNCH (-2)
+#define ARCVAE_ERR_DEVICE (-3)
+
+#define ARCVAE_GEMM_ACCUMULATE 1 /* C += ...                                   */
+#define ARCVAE_GEMM_TANH 2       /* C = tanh(...)                              */
+#define ARCVAE_GEMM_SPLITK 4     /* allow split-K with f32 atomics             */
+#define ARCVAE_GEMM_NO_SKINNY 8  /* force the tile kernel                      */
+
+typedef void* arcvae_stream_t; /* hipStream_t */
+
+/* ABI version / build probe: returns 1000*major + minor; *arch_gfx950 = 1 when the code object
+ * was built for gfx950. */
+int arcvae_abi_version(int* arch_gfx950);
+
+/* ---- generic contraction (MLX addmm / matmul, M2: y = x W^T + b) -------------------------
+ * C[M,N] (+)= op(A) op(B) (+ bias[N]); transA=0: A [M,K], transA=1: A stored [K,M];
+ * transB=0: B [K,N], transB=1: B stored [N,K].  Replaces every nn.Linear / matmul on the path,
+ * e.g. models/encoder.py:109,115,117,118 and models/decoder.py:175. */
+int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                    const float* B, int ldb, float* C, int ldc, const float* bias, int flags,
+                    arcvae_stream_t stream);
+
+/* ---- encoder LSTM stack -------------------------------------------------------------------
+ * models/encoder.py:93-101: embedding lookup + L stacked nn.LSTM over the full padded sequence
+ * (MLX nn.LSTM semantics M1: gates i,f,g,o; t=0 has no recurrent term and c_0 = i*g).
+ * x_tb [T,B] int32 tokens (time-major; arcvae_transpose_tokens makes it from [B,T]);
+ * table0 [V,4H] = embedding . Wx_0^T + bias_0 (one arcvae_gemm_f32 call);
+ * outputs hseq,cseq [L,T,B,H], gseq [L,T,B,4H] (post-activation gates, saved for BPTT). */
+int arcvae_transpose_tokens(const int32_t* src_bt, int32_t* dst_tb, int B, int T, arcvae_stream_t stream);
+int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
+                            const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
+                            float* gseq, int B, int T, int V, int H, int L, arcvae_stream_t stream);
+/* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
+ * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
+ * position read by models/encoder.py:106.  dG out [L,T,B,4H]; dcs ws [L,T,B,H]; wT ws [(2L-1),H,4H]. */
+int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
+                             const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
+                             float* wT, int B, int T, int H, int L, arcvae_stream_t stream);
+/* Parameter gradients of the stack from dG: embedding.weight, lstm_layer_l.{Wx,Wh,bias}. */
+int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
+                          const float* dG, float* dtable_ws, float* dEmb, float* const* dWx,
+                          float* const* dWh, float* const* dbias, int B, int T, int V, int E, int H, int L,
+                          arcvae_stream_t stream);
+
+/* ---- encoder heads + reparameterisation + latent loss ----------------------------------------
+ * models/encoder.py:106-130 (condition_fc, fc_mu, fc_logvar_hidden, fc_logvar, tanh bounds),
+ * models/encoder.py:147-153 (z = mu + eps*exp(logvar/2), eps injected), and the per-rank halves
+ * of losses/kl.py:39-56 and losses/info.py:27-41.  stats [2Z+4] is zeroed and filled here. */
+int arcvae_enc_heads_forward(const float* hT, const float* cond, const float* Wc, const float* bc,
+                             const float* Wmu, const float* bmu, const float* Wlh, const float* blh,
+                             const float* Wlv, const float* blv, const float* eps, float* comb, float* lh,
+                             float* mu_raw, float* lv_raw, float* mu, float* logvar, float* z, float* stats,
+                             int B, int H, int Z, int C, float free_bits, arcvae_stream_t stream);
+int arcvae_stats_set_recon(const float* rowloss, int B, float* stats, int Z, arcvae_stream_t stream);
+/* complete_vae_loss.py:45-99 (+ losses/kl.py, losses/info.py reductions) from GLOBAL stats.
+ * hyper [8] device: beta, lambda_collapse, lambda_mi, target_mi, free_bits; scalars [16] device out:
+ * total, recon, kl, beta*kl, collapse, prop(0), lambda_prop*prop(0), mutual_info, mi_penalty.
+ * dmu_raw/dlv_raw [B,Z] may be NULL (forward only). */
+int arcvae_latent_loss(const float* stats, const float* hyper, const float* mu, const float* logvar,
+                       float* scalars, float* dmu_raw, float* dlv_raw, int B, int Z, int T, float free_bits,
+                       arcvae_stream_t stream);
+int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* Wlh, const float* Wlv,
+                              const float* comb, const float* lh, const float* dmu_raw, const float* dlv_raw,
+                              float* dlh, float* dcomb, float* dWc, float* dbc, float* dWmu, float* dbmu,
+                              float* dWlh, float* dblh, float* dWlv, float* dblv, int B, int H, int Z, int C,
+                              arcvae_stream_t stream);
+
+/* ---- decoder, vocabulary-dense ------------------------------------------------------------------
+ * models/decoder.py:152-175: per step embed(token) ++ conditions -> L zero-state LSTM cells
+ * (hidden=None, cell=None every call, Q1) -> fc_out.  logits_t depends only on (token_t, cond_b),
+ * so all B*V (row, token) pairs are evaluated at once: logits [B*V,V], lse [B*V], nxt [B*V]
+ * (mode 0: first argmax(logits), decoder.py:185; mode 1: first argmax(softmax(logits/temperature)),
+ * decoder_sampling.py:110-117). */
+int arcvae_dec_forward_dense(const float* emb, const float* const* Wx, const float* const* bias,
+                             const float* Wout, const float* bout, const float* cond, float* tableD,
+                             float* hact, float* gpre, float* logits, float* lse, int32_t* nxt, int B, int V,
+                             int E, int C, int H, int L, int mode, float temperature, arcvae_stream_t stream);
+/* models/decoder.py:146-185 teacher-forcing walk (coins[t] = np.random.rand() < ratio, Q5) fused
+ * with losses/recon.py:29-60 row sums: fed [B,T], rowloss [B] = sum_t CE. */
+int arcvae_dec_chain_ce(const int32_t* x, const uint8_t* coins, const int32_t* nxt, const float* lse,
+                        const float* logits, int32_t* fed, float* rowloss, int B, int T, int V,
+                        arcvae_stream_t stream);
+/* d(recon)/d(dense logits); inv_count = 1/(B_global*T) (mean over ALL positions, Q3). */
+int arcvae_dec_ce_backward(const int32_t* x, const int32_t* fed, const float* logits, const float* lse,
+                           float* dlogits, int B, int T, int V, float inv_count, arcvae_stream_t stream);
+/* out[b,t,:] = dense[b, fed[b,t], :]: the [B,T,V] logits of models/decoder.py:188. */
+int arcvae_dec_gather_logits(const float* dense, const int32_t* fed, float* out, int B, int T, int V,
+                             arcvae_stream_t stream);
+/* models/decoder_sampling.py:85-123 greedy walk: tokens [B,max_len], first_end [B]. */
+int arcvae_dec_sample_chain(const int32_t* nxt, int32_t* tokens, int32_t* first_end, int B, int V,
+                            int max_len, int end_token, arcvae_stream_t stream);
+/* Backward of arcvae_dec_forward_dense: embedding.weight, lstm_layer_l.{Wx,bias}, fc_out.{weight,bias}.
+ * ws: dh [2,B*V,H], dG [B*V,4H], dtableD [V,4H], wcpart [V,4H,max(C,1)]. */
+int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const float* const* bias,
+                              const float* Wout, const float* cond, const float* tableD, const float* hact,
+                              const float* gpre, const float* dlogits, float* dh, float* dG, float* dtableD,
+                              float* wcpart, float* dEmb, float* const* dWx, float* const* dbias, float* dWout,
+                              float* dbout, int B, int V, int E, int C, int H, int L, arcvae_stream_t stream);
+
+/* ---- optimizer ------------------------------------------------------------------------------------
+ * trainer.py:75-76,320,324: MLX optim.Adam, NO bias correction (Q7):
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p = p - lr m / (sqrt(v) + eps), over a flat buffer. */
+int arcvae_adam_update(float* params, const float* grads, float* m, float* v, long n, double lr,
+                       double beta1, double beta2, double eps, arcvae_stream_t stream);
+
+/* ---- small helpers ---------------------------------------------------------------------------------- */
+int arcvae_colsum_accum(const float* X, int rows, int cols, int ld, float* out, float scale,
+                        arcvae_stream_t stream);
+int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int rows, int nseg, int cols, float* out,
+                             arcvae_stream_t stream);
+int arcvae_transpose_batched(const float* const* src, float* const* dst, const int* rows, const int* cols,
+                             int n, arcvae_stream_t stream);
+int arcvae_scale_inplace(float* x, long n, float s, arcvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCVAE_HIP_H */

@@ -1,0 +1,294 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32).
+//
+// The reference computes everything in float32 (MLX default dtype) and
+// parity is stated at 1e-4 relative, so the contractions run on the *exact-f32* MFMA
+// forms (bitwise an fmaf chain; gfx950 has no xf32/TF32).  Their peak is the f32 vector
+// peak (157 TFLOP/s) -- the roofline this file is measured against.
+//
+//   C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N]) (tanh)
+//   transA = 0: A stored [M,K] row-major (K contiguous)   transA = 1: A stored [K,M]
+//   transB = 0: B stored [K,N] row-major (N contiguous)   transB = 1: B stored [N,K]
+//
+// Two kernels:
+//   * tile kernel: BMxBN block tile (128x128 or 64x64), BK = 16, 4 waves in 2x2, register
+//     prefetch of the next K-tile + double-buffered LDS (one barrier per K-tile); optional
+//     split-K over gridDim.z with f32 atomics for the K-long / small-MN weight-gradient shapes.
+//   * skinny kernel (skinny.h): 16x16 tile per block, K split over the 4 waves -- used when M is
+//     a minibatch (<= 256 rows) and the op is on the step's critical path.
+#include "common.h"
+#include "skinny.h"
+
+namespace {
+
+struct GemmP {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int accumulate;  // C += result (non-split path)
+    int act;         // 0 none, 1 tanh
+    int kchunk;      // K range per blockIdx.z (multiple of 16)
+};
+
+constexpr int BK = 16;
+constexpr int PAD = 4;
+
+// Loader for one operand tile [ROWS x BK], staged in LDS k-major: S[k][ROWS+PAD].
+// KCONTIG: element (r,k) at P[r*ld + k]; else at P[k*ld + r].
+template <int ROWS, bool KCONTIG, int VEC>
+struct TileLoader {
+    static constexpr int NV = (ROWS * BK) / (256 * VEC);
+    float4 v4[VEC == 4 ? NV : 1];
+    float v1[VEC == 1 ? NV : 1];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int rmax,
+                                         int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            if constexpr (VEC == 4) {
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (KCONTIG) {
+                    const int r = r0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+                    if (r < rmax && k < kend) z = *reinterpret_cast<const float4*>(P + (long)r * ld + k);
+                } else {
+                    const int k = k0 + idx / (ROWS / 4), r = r0 + (idx % (ROWS / 4)) * 4;
+                    if (r < rmax && k < kend) z = *reinterpret_cast<const float4*>(P + (long)k * ld + r);
+                }
+                v4[i] = z;
+            } else {
+                float z = 0.f;
+                if constexpr (KCONTIG) {
+                    const int r = r0 + (idx >> 4), k = k0 + (idx & 15);
+                    if (r < rmax && k < kend) z = P[(long)r * ld + k];
+                } else {
+                    const int k = k0 + idx / ROWS, r = r0 + idx % ROWS;
+                    if (r < rmax && k < kend) z = P[(long)k * ld + r];
+                }
+                v1[i] = z;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* S, int tid) const {
+        constexpr int LD = ROWS + PAD;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            if constexpr (VEC == 4) {
+                if constexpr (KCONTIG) {
+                    const int r = idx >> 2, k = (idx & 3) * 4;
+                    S[(k + 0) * LD + r] = v4[i].x;
+                    S[(k + 1) * LD + r] = v4[i].y;
+                    S[(k + 2) * LD + r] = v4[i].z;
+                    S[(k + 3) * LD + r] = v4[i].w;
+                } else {
+                    const int k = idx / (ROWS / 4), r = (idx % (ROWS / 4)) * 4;
+                    *reinterpret_cast<float4*>(S + k * LD + r) = v4[i];
+                }
+            } else {
+                if constexpr (KCONTIG) {
+                    const int r = idx >> 4, k = idx & 15;
+                    S[k * LD + r] = v1[i];
+                } else {
+                    const int k = idx / ROWS, r = idx % ROWS;
+                    S[k * LD + r] = v1[i];
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool AK, bool BKC, int VA, int VB>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
+    constexpr int WM = BM / 2, WN = BN / 2;   // wave tile (2x2 waves)
+    constexpr int MT = WM / 32, NT = WN / 32;  // 32x32 MFMA tiles per wave
+    constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA_S + LDB_S)];
+    float* const As0 = smem;                   // As[buf] = As0 + buf * BK * LDA_S
+    float* const Bs0 = smem + 2 * BK * LDA_S;  // Bs[buf] = Bs0 + buf * BK * LDB_S
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileLoader<BM, AK, VA> la;
+    TileLoader<BN, BKC, VB> lb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+        la.store(As0, tid);
+        lb.store(Bs0, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            la.load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+            lb.load(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
+        }
+        const float* as = As0 + cur * BK * LDA_S + (lane >> 5) * LDA_S + wm * WM + (lane & 31);
+        const float* bs = Bs0 + cur * BK * LDB_S + (lane >> 5) * LDB_S + wn * WN + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = as[kk * LDA_S + i * 32];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = bs[kk * LDB_S + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            la.store(As0 + (cur ^ 1) * BK * LDA_S, tid);
+            lb.store(Bs0 + (cur ^ 1) * BK * LDB_S, tid);
+        }
+        __syncthreads();
+    }
+
+    const bool split = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * WN + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            const float bv = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float* c = p.C + (long)row * p.ldc + col;
+                float v = acc[i][j][r] + bv;
+                if (split) {
+                    atomicAdd(c, v);
+                } else {
+                    if (p.accumulate) v += *c;
+                    if (p.act == 1) v = tanhf(v);
+                    *c = v;
+                }
+            }
+        }
+}
+
+// Skinny: 16x16 tile per block; A [M,K] K-contiguous; B either [N,K] (BKC) or [K,N].
+template <bool BKC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
+    __shared__ float red[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int arow = min(m0 + (lane & 15), p.M - 1);
+    const int bcol = min(n0 + (lane & 15), p.N - 1);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BKC)
+        skinny_accum_kk(acc0, acc1, p.A, (long)arow * p.lda, p.B, (long)bcol * p.ldb, p.K, wave, lane);
+    else
+        skinny_accum_kn(acc0, acc1, p.A, (long)arow * p.lda, p.B, p.ldb, bcol, p.K, wave, lane);
+    skinny_store_partial(red, acc0, acc1, wave, lane);
+    __syncthreads();
+    const int row = tid >> 4, col = tid & 15;
+    const int gr = m0 + row, gc = n0 + col;
+    if (gr < p.M && gc < p.N) {
+        float v = skinny_reduced(red, row, col);
+        if (p.bias) v += p.bias[gc];
+        float* c = p.C + (long)gr * p.ldc + gc;
+        if (p.accumulate) v += *c;
+        if (p.act == 1) v = tanhf(v);
+        *c = v;
+    }
+}
+
+template <int BM, int BN, bool AK, bool BKC>
+void launch_tile(const GemmP& p, dim3 grid, bool va4, bool vb4, hipStream_t s) {
+    if (va4 && vb4)
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 4, 4>), grid, dim3(256), 0, s, p);
+    else if (va4)
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 4, 1>), grid, dim3(256), 0, s, p);
+    else if (vb4)
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 1, 4>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 1, 1>), grid, dim3(256), 0, s, p);
+}
+
+template <int BM, int BN>
+void launch_tile_t(const GemmP& p, dim3 grid, bool ak, bool bk, bool va4, bool vb4, hipStream_t s) {
+    if (ak && bk) launch_tile<BM, BN, true, true>(p, grid, va4, vb4, s);
+    else if (ak) launch_tile<BM, BN, true, false>(p, grid, va4, vb4, s);
+    else if (bk) launch_tile<BM, BN, false, true>(p, grid, va4, vb4, s);
+    else launch_tile<BM, BN, false, false>(p, grid, va4, vb4, s);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+#define ARCVAE_GEMM_ACCUMULATE 1
+#define ARCVAE_GEMM_TANH 2
+#define ARCVAE_GEMM_SPLITK 4
+#define ARCVAE_GEMM_NO_SKINNY 8
+
+extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
+                               const float* A, int lda, const float* B, int ldb,
+                               float* C, int ldc, const float* bias, int flags, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return ARCVAE_ERR_ARG;
+    if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return ARCVAE_ERR_ARG;
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.accumulate = (flags & ARCVAE_GEMM_ACCUMULATE) ? 1 : 0;
+    p.act = (flags & ARCVAE_GEMM_TANH) ? 1 : 0;
+    p.kchunk = ((K + BK - 1) / BK) * BK;
+
+    const bool ak = !transA, bk = transB != 0;
+    // Skinny path: minibatch-sized M on the critical path.
+    if (!(flags & ARCVAE_GEMM_NO_SKINNY) && ak && M <= 256 && (K % 64) == 0 && (lda % 4) == 0 &&
+        aligned16(A) && (!bk || ((ldb % 4) == 0 && aligned16(B)))) {
+        dim3 grid(ceil_div(N, 16), ceil_div(M, 16), 1);
+        if (bk) hipLaunchKernelGGL(gemm_skinny_kernel<true>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(gemm_skinny_kernel<false>, grid, dim3(256), 0, stream, p);
+        return arcvae_launch_status();
+    }
+
+    // vector (16-byte) global loads need the contiguous extent and the leading dimension to be
+    // multiples of 4 floats and an aligned base; otherwise scalar loads (e.g. ld = E+C = 129).
+    const bool va4 = aligned16(A) && (lda % 4) == 0 && ((ak ? K : M) % 4) == 0;
+    const bool vb4 = aligned16(B) && (ldb % 4) == 0 && ((bk ? K : N) % 4) == 0;
+
+    const bool big = (M >= 256 && N >= 128) || (M >= 128 && N >= 256);
+    const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+    dim3 grid(ceil_div(N, bn), ceil_div(M, bm), 1);
+    if ((flags & ARCVAE_GEMM_SPLITK) && p.act == 0) {
+        const int blocks = grid.x * grid.y;
+        int want = ceil_div(512, blocks);
+        const int maxz = max(1, K / 128);  // at least 128 of K per slice
+        int z = min(want, maxz);
+        if (z > 1) {
+            p.kchunk = ceil_div(ceil_div(K, z), BK) * BK;
+            z = ceil_div(K, p.kchunk);
+            grid.z = z;
+            if (!p.accumulate) {
+                if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, stream) != hipSuccess)
+                    return ARCVAE_ERR_LAUNCH;
+            }
+        }
+    }
+    if (big) launch_tile_t<128, 128>(p, grid, ak, bk, va4, vb4, stream);
+    else launch_tile_t<64, 64>(p, grid, ak, bk, va4, vb4, stream);
+    return arcvae_launch_status();
+}

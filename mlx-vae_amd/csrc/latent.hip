@@ -1,0 +1,269 @@
+// Encoder heads, reparameterisation and the latent part of the loss
+// (reference models/encoder.py:106-153, losses/kl.py:35-66, losses/info.py:23-78,
+//  complete_vae_loss.py:45-99), forward and hand-written backward.
+//
+// The mutual-information term uses BATCH statistics, so the loss is computed in
+// two halves with a reduction seam between them: `heads_forward` leaves per-rank partial sums
+// in `stats` (2Z+4 floats; under data parallelism these are all-reduced), `latent_loss` turns
+// the (global) sums into the loss scalars and d/d(mu_raw), d/d(logvar_raw) for the local rows.
+//
+// stats layout: [0,Z) sum_b mu   [Z,2Z) sum_b exp(logvar)   [2Z] sum_b KL_b (unclamped, MI form)
+//               [2Z+1] sum_b KL_b (clamped >= 0, free bits)   [2Z+2] rows   [2Z+3] sum_b CE row sums
+// hyper layout (device, so a captured graph follows the epoch schedules):
+//               [0] beta [1] lambda_collapse [2] lambda_mi [3] target_mi [4] free_bits
+// scalars out:  [0] total [1] recon [2] kl [3] beta*kl [4] collapse [5] prop(=0) [6] lambda_prop*prop(=0)
+//               [7] mutual_info [8] mi_penalty [9] d(total)/d(mi_raw) [10] global rows
+#include "ops.h"
+
+namespace {
+
+// comb[b, :H] = hT[b, :];  comb[b, H + j] = bc[j] + sum_c cond[b,c] * Wc[j,c]   (encoder.py:106-112)
+__global__ __launch_bounds__(256) void build_comb_kernel(const float* __restrict__ hT,
+                                                         const float* __restrict__ cond,
+                                                         const float* __restrict__ Wc,
+                                                         const float* __restrict__ bc, float* comb, int B, int H,
+                                                         int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 2 * H) return;
+    const int b = idx / (2 * H), j = idx % (2 * H);
+    float v;
+    if (j < H) {
+        v = hT[(long)b * H + j];
+    } else {
+        const int u = j - H;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += cond[b * C + c] * Wc[u * C + c];
+        v = s + bc[u];
+    }
+    comb[idx] = v;
+}
+
+__device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// mu = 2 tanh(mu_raw/2); logvar = tanh(lv_raw/2) - 1; z = mu + eps*exp(logvar/2); partial stats.
+// Block = 64 rows x all Z columns (threads stride over Z).
+__global__ __launch_bounds__(256) void latent_apply_kernel(const float* __restrict__ mu_raw,
+                                                           const float* __restrict__ lv_raw,
+                                                           const float* __restrict__ eps, float* mu, float* logvar,
+                                                           float* z, float* stats, int B, int Z, float fb_min) {
+    __shared__ float red[2][4];
+    const int r0 = blockIdx.x * 64, r1 = min(B, r0 + 64);
+    float klmi = 0.f, klfb = 0.f;
+    for (int j = threadIdx.x; j < Z; j += 256) {
+        float smu = 0.f, svar = 0.f;
+        for (int b = r0; b < r1; ++b) {
+            const long i = (long)b * Z + j;
+            const float m = tanhf(mu_raw[i] / 2.0f) * 2.0f;
+            const float lv = tanhf(lv_raw[i] / 2.0f) * 1.0f - 1.0f;
+            mu[i] = m;
+            logvar[i] = lv;
+            z[i] = m + eps[i] * expf(0.5f * lv);
+            const float mc = clipf(m, -3.0f, 3.0f), lc = clipf(lv, -6.0f, 3.0f);
+            const float var = expf(lc);
+            const float k = -0.5f * (1.0f + lc - mc * mc - var);
+            smu += mc;
+            svar += var;
+            klmi += k;
+            float kf = fmaxf(k, 0.0f);
+            if (fb_min > 0.0f) kf = fmaxf(kf, fb_min);
+            klfb += kf;
+        }
+        atomicAdd(stats + j, smu);
+        atomicAdd(stats + Z + j, svar);
+    }
+    klmi = wave_sum(klmi);
+    klfb = wave_sum(klfb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = klmi; red[1][wave] = klfb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + 2 * Z, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        atomicAdd(stats + 2 * Z + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        atomicAdd(stats + 2 * Z + 2, (float)(r1 - r0));
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_to_kernel(const float* __restrict__ x, int n, float* out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One block: loss scalars from the (global) stats.
+__global__ __launch_bounds__(256) void latent_scalars_kernel(const float* __restrict__ stats,
+                                                             const float* __restrict__ hyper, float* scalars,
+                                                             int Z, int T) {
+    __shared__ float red[4];
+    const float Bg = stats[2 * Z + 2];
+    float a = 0.f;
+    for (int j = threadIdx.x; j < Z; j += 256) {
+        const float mm = stats[j] / Bg, mv = stats[Z + j] / Bg;
+        a += 1.0f + logf(mv) - mm * mm - mv;
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float agg = -0.5f * ((red[0] + red[1]) + (red[2] + red[3]));
+        const float beta = hyper[0], lc = hyper[1], lmi = hyper[2], target = hyper[3];
+        const float mean_kl = stats[2 * Z] / Bg;
+        const float mi_raw = mean_kl - agg;
+        const float mi = mi_raw > 0.0f ? mi_raw : 0.0f;       // mx.maximum(mi, 0.0): grad iff mi_raw > 0
+        const float d = target - mi;
+        const bool gate = !(0.0f > d);                        // mx.maximum(0.0, d): grad to d iff 0 <= d
+        const float dpos = gate ? d : 0.0f;
+        const float collapse = lc * dpos, mi_pen = lmi * dpos;
+        const float kl = stats[2 * Z + 1] / Bg;
+        const float recon = stats[2 * Z + 3] / (Bg * (float)T);
+        const float wkl = beta * kl;
+        scalars[0] = recon + wkl + collapse + 0.0f + mi_pen;
+        scalars[1] = recon;
+        scalars[2] = kl;
+        scalars[3] = wkl;
+        scalars[4] = collapse;
+        scalars[5] = 0.0f;
+        scalars[6] = 0.0f;
+        scalars[7] = mi;
+        scalars[8] = mi_pen;
+        scalars[9] = (gate && mi_raw > 0.0f) ? -(lc + lmi) : 0.0f;
+        scalars[10] = Bg;
+    }
+}
+
+// d(total)/d(mu_raw), d(total)/d(lv_raw) for the local rows (z carries no gradient, Q2).
+__global__ __launch_bounds__(256) void latent_grad_kernel(const float* __restrict__ mu,
+                                                          const float* __restrict__ logvar,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ hyper,
+                                                          const float* __restrict__ scalars, float* dmu_raw,
+                                                          float* dlv_raw, int B, int Z, float fb_min) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Z) return;
+    const int j = idx % Z;
+    const float Bg = stats[2 * Z + 2];
+    const float beta = hyper[0], cmi = scalars[9];
+    const float m = mu[idx], lv = logvar[idx];
+    // clip pass-through masks (mx.clip = minimum(maximum(x, lo), hi); never active inside the tanh bounds)
+    const float pm = (m > -3.0f && m < 3.0f) ? 1.0f : 0.0f;
+    const float pl = (lv > -6.0f && lv < 3.0f) ? 1.0f : 0.0f;
+    const float mc = clipf(m, -3.0f, 3.0f), lc = clipf(lv, -6.0f, 3.0f);
+    const float var = expf(lc);
+    const float k = -0.5f * (1.0f + lc - mc * mc - var);
+    const bool live = (k > 0.0f) && !(fb_min > 0.0f && !(k > fb_min));
+    float gm = 0.f, gl = 0.f;
+    if (live) {
+        gm += beta * mc / Bg;
+        gl += beta * 0.5f * (var - 1.0f) / Bg;
+    }
+    if (cmi != 0.0f) {
+        const float mm = stats[j] / Bg, mv = stats[Z + j] / Bg;
+        gm += cmi * (mc - mm) / Bg;
+        gl += cmi * 0.5f * (var / mv - 1.0f) / Bg;
+    }
+    gm *= pm;
+    gl *= pl;
+    const float hm = 0.5f * m;          // tanh(mu_raw/2)
+    const float hl = lv + 1.0f;         // tanh(lv_raw/2)
+    dmu_raw[idx] = gm * (1.0f - hm * hm);
+    dlv_raw[idx] = gl * 0.5f * (1.0f - hl * hl);
+}
+
+// y = dy_in * (1 - t^2)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ t, float* d, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float tv = t[i];
+        d[i] = d[i] * (1.0f - tv * tv);
+    }
+}
+
+}  // namespace
+
+// Reference models/encoder.py:106-153 (+ the per-rank halves of kl.py / info.py reductions).
+//   hT [B,H] = top-layer h at the LAST padded position (Q3); eps [B,Z] injected N(0,1) noise (Q18)
+//   ws/out: comb [B,2H], lh [B,2H], mu_raw/lv_raw [B,Z], mu/logvar/z [B,Z], stats [2Z+4] (zeroed here)
+extern "C" int arcvae_enc_heads_forward(const float* hT, const float* cond, const float* Wc, const float* bc,
+                                        const float* Wmu, const float* bmu, const float* Wlh, const float* blh,
+                                        const float* Wlv, const float* blv, const float* eps, float* comb,
+                                        float* lh, float* mu_raw, float* lv_raw, float* mu, float* logvar,
+                                        float* z, float* stats, int B, int H, int Z, int C, float free_bits,
+                                        hipStream_t stream) {
+    if (!hT || !cond || !Wc || !bc || !Wmu || !bmu || !Wlh || !blh || !Wlv || !blv || !eps || !comb || !lh ||
+        !mu_raw || !lv_raw || !mu || !logvar || !z || !stats)
+        return ARCVAE_ERR_ARG;
+    if (B <= 0 || H <= 0 || Z <= 0 || C < 0) return ARCVAE_ERR_ARG;
+    const int H2 = 2 * H;
+    hipLaunchKernelGGL(build_comb_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, hT, cond, Wc, bc, comb,
+                       B, H, C);
+    int rc = arcvae_gemm_f32(0, 1, B, Z, H2, comb, H2, Wmu, H2, mu_raw, Z, bmu, 0, stream);
+    if (rc) return rc;
+    rc = arcvae_gemm_f32(0, 1, B, H2, H2, comb, H2, Wlh, H2, lh, H2, blh, ARCVAE_GEMM_TANH, stream);
+    if (rc) return rc;
+    rc = arcvae_gemm_f32(0, 1, B, Z, H2, lh, H2, Wlv, H2, lv_raw, Z, blv, 0, stream);
+    if (rc) return rc;
+    if (hipMemsetAsync(stats, 0, (size_t)(2 * Z + 4) * sizeof(float), stream) != hipSuccess) return ARCVAE_ERR_LAUNCH;
+    const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
+    hipLaunchKernelGGL(latent_apply_kernel, dim3(ceil_div(B, 64)), dim3(256), 0, stream, mu_raw, lv_raw, eps, mu,
+                       logvar, z, stats, B, Z, fb_min);
+    return arcvae_launch_status();
+}
+
+// stats[2Z+3] = sum_b rowloss[b]  (CE row sums from arcvae_dec_chain_ce)
+extern "C" int arcvae_stats_set_recon(const float* rowloss, int B, float* stats, int Z, hipStream_t stream) {
+    if (!rowloss || !stats || B <= 0 || Z <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(sum_to_kernel, dim3(1), dim3(256), 0, stream, rowloss, B, stats + 2 * Z + 3);
+    return arcvae_launch_status();
+}
+
+// Loss scalars (complete_vae_loss.py:45-99) from GLOBAL stats, and the latent gradients of the
+// local rows.  hyper/scalars/stats are device arrays (layouts at the top of this file).
+extern "C" int arcvae_latent_loss(const float* stats, const float* hyper, const float* mu, const float* logvar,
+                                  float* scalars, float* dmu_raw, float* dlv_raw, int B, int Z, int T,
+                                  float free_bits, hipStream_t stream) {
+    if (!stats || !hyper || !mu || !logvar || !scalars || B <= 0 || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(latent_scalars_kernel, dim3(1), dim3(256), 0, stream, stats, hyper, scalars, Z, T);
+    if (dmu_raw && dlv_raw) {
+        const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
+        hipLaunchKernelGGL(latent_grad_kernel, dim3(ceil_div(B * Z, 256)), dim3(256), 0, stream, mu, logvar, stats,
+                           hyper, scalars, dmu_raw, dlv_raw, B, Z, fb_min);
+    }
+    return arcvae_launch_status();
+}
+
+// Backward of the heads: parameter gradients ("+=") and dcomb [B,2H] (its first H columns are
+// d/d(hT), consumed by arcvae_enc_lstm_backward with ld = 2H).   ws: dlh [B,2H]
+extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* Wlh, const float* Wlv,
+                                         const float* comb, const float* lh, const float* dmu_raw,
+                                         const float* dlv_raw, float* dlh, float* dcomb, float* dWc, float* dbc,
+                                         float* dWmu, float* dbmu, float* dWlh, float* dblh, float* dWlv,
+                                         float* dblv, int B, int H, int Z, int C, hipStream_t stream) {
+    if (!cond || !Wmu || !Wlh || !Wlv || !comb || !lh || !dmu_raw || !dlv_raw || !dlh || !dcomb || !dWc || !dbc ||
+        !dWmu || !dbmu || !dWlh || !dblh || !dWlv || !dblv)
+        return ARCVAE_ERR_ARG;
+    const int H2 = 2 * H;
+    const int ACC = ARCVAE_GEMM_ACCUMULATE;
+    int rc;
+    // fc_mu
+    if ((rc = arcvae_gemm_f32(1, 0, Z, H2, B, dmu_raw, Z, comb, H2, dWmu, H2, nullptr, ACC, stream))) return rc;
+    if ((rc = arcvae_colsum_accum(dmu_raw, B, Z, Z, dbmu, 1.0f, stream))) return rc;
+    if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dmu_raw, Z, Wmu, H2, dcomb, H2, nullptr, 0, stream))) return rc;
+    // fc_logvar
+    if ((rc = arcvae_gemm_f32(1, 0, Z, H2, B, dlv_raw, Z, lh, H2, dWlv, H2, nullptr, ACC, stream))) return rc;
+    if ((rc = arcvae_colsum_accum(dlv_raw, B, Z, Z, dblv, 1.0f, stream))) return rc;
+    if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dlv_raw, Z, Wlv, H2, dlh, H2, nullptr, 0, stream))) return rc;
+    // tanh(fc_logvar_hidden)
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, lh, dlh, (long)B * H2);
+    if ((rc = arcvae_gemm_f32(1, 0, H2, H2, B, dlh, H2, comb, H2, dWlh, H2, nullptr, ACC, stream))) return rc;
+    if ((rc = arcvae_colsum_accum(dlh, B, H2, H2, dblh, 1.0f, stream))) return rc;
+    if ((rc = arcvae_gemm_f32(0, 0, B, H2, H2, dlh, H2, Wlh, H2, dcomb, H2, nullptr, ACC, stream))) return rc;
+    // condition_fc: dcr = dcomb[:, H:]
+    if (C > 0) {
+        if ((rc = arcvae_gemm_f32(1, 0, H, C, B, dcomb + H, H2, cond, C, dWc, C, nullptr, ACC, stream))) return rc;
+    }
+    if ((rc = arcvae_colsum_accum(dcomb + H, B, H, H2, dbc, 1.0f, stream))) return rc;
+    return arcvae_launch_status();
+}

@@ -1,0 +1,208 @@
+// HBM-bound helper kernels: column sums, small transposes, segment (token) sums, and the
+// fused un-bias-corrected Adam (reference trainer.py:75-76,320,324 -> MLX optim.Adam, Q7).
+#include "ops.h"
+
+namespace {
+
+// ---- colsum: out[c] += scale * sum_r X[r, c] ------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int rows, int cols,
+                                                     int ld, float* out, float scale, int rows_per_blk) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int rbeg = blockIdx.y * rows_per_blk, rend = min(rows, rbeg + rows_per_blk);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = rbeg + rl; r < rend; r += 4) s += X[(long)r * ld + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        atomicAdd(out + c, s * scale);
+    }
+}
+
+// ---- batched 2-D transpose -------------------------------------------------------------
+struct TrJobs {
+    const float* src[16];
+    float* dst[16];
+    int rows[16];
+    int cols[16];
+};
+__global__ __launch_bounds__(256) void transpose_kernel(TrJobs j) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z;
+    const int R = j.rows[z], Cc = j.cols[z];
+    const float* __restrict__ s = j.src[z];
+    float* d = j.dst[z];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (c0 >= Cc || r0 >= R) return;  // whole block out of range for this (smaller) job
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        if (r < R && c < Cc) tile[ty + i][tx] = s[(long)r * Cc + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (r < R && c < Cc) d[(long)c * R + r] = tile[tx][ty + i];
+    }
+}
+
+// ---- segment sum: out[seg[r], :] += X[r, :] --------------------------------------------
+// Block = 64 columns x 4 row lanes over a 256-row chunk; per-block [nseg][64] table in LDS
+// (ds_add_f32), flushed with one global f32 atomic per touched entry.
+__global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ X, const int32_t* __restrict__ seg,
+                                                     int rows, int nseg, int cols, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    for (int i = threadIdx.x; i < nseg * 64; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int rbeg = blockIdx.y * 256, rend = min(rows, rbeg + 256);
+    if (c < cols) {
+        for (int r = rbeg + rl; r < rend; r += 4) {
+            int sgm = seg[r];
+            sgm = min(max(sgm, 0), nseg - 1);
+            atomicAdd(&tab[sgm * 64 + cl], X[(long)r * cols + c]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nseg * 64; i += 256) {
+        const float v = tab[i];
+        const int cc = blockIdx.x * 64 + (i & 63);
+        if (v != 0.f && cc < cols) atomicAdd(out + (long)(i >> 6) * cols + cc, v);
+    }
+}
+
+__global__ void transpose_tokens_kernel(const int32_t* __restrict__ src, int32_t* dst, int B, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * T) {
+        const int t = i / B, b = i % B;
+        dst[i] = src[b * T + t];
+    }
+}
+
+// ---- Adam without bias correction (MLX optim.Adam default) ------------------
+//   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p = p - lr*m/(sqrt(v)+eps)
+// One launch over the flat [encoder | decoder] parameter buffer: the reference's two optimizers
+// share lr/betas/eps and Adam state is elementwise, so one flat pass is the same update.
+// HBM-bound: 4 streams read + 3 written = 28 B/param.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n4, long n,
+                                                   float lr, float b1, float b2, float omb1, float omb2, float eps) {
+#pragma clang fp contract(off)
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(c)                                   \
+        mm.c = b1 * mm.c + omb1 * gg.c;            \
+        vv.c = b2 * vv.c + omb2 * (gg.c * gg.c);   \
+        pp.c = pp.c - (lr * mm.c) / (sqrtf(vv.c) + eps);
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // scalar tail
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * (gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - (lr * mi) / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ void scale_kernel(float* x, long n, float s) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= s;
+}
+
+}  // namespace
+
+extern "C" int arcvae_colsum_accum(const float* X, int rows, int cols, int ld, float* out, float scale,
+                                   hipStream_t stream) {
+    if (!X || !out || rows <= 0 || cols <= 0 || ld < cols) return ARCVAE_ERR_ARG;
+    int nchunks = min(ceil_div(rows, 64), 128);
+    const int rpb = ceil_div(rows, nchunks);
+    nchunks = ceil_div(rows, rpb);
+    dim3 grid(ceil_div(cols, 64), nchunks);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, rows, cols, ld, out, scale, rpb);
+    return arcvae_launch_status();
+}
+
+extern "C" int arcvae_transpose_batched(const float* const* src, float* const* dst, const int* rows,
+                                        const int* cols, int n, hipStream_t stream) {
+    if (n <= 0 || n > 16) return ARCVAE_ERR_ARG;
+    TrJobs j;
+    int maxr = 0, maxc = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i] || rows[i] <= 0 || cols[i] <= 0) return ARCVAE_ERR_ARG;
+        j.src[i] = src[i]; j.dst[i] = dst[i]; j.rows[i] = rows[i]; j.cols[i] = cols[i];
+        maxr = max(maxr, rows[i]); maxc = max(maxc, cols[i]);
+    }
+    for (int i = n; i < 16; ++i) { j.src[i] = nullptr; j.dst[i] = nullptr; j.rows[i] = 0; j.cols[i] = 0; }
+    dim3 grid(ceil_div(maxc, 32), ceil_div(maxr, 32), n);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, j);
+    return arcvae_launch_status();
+}
+
+extern "C" int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int rows, int nseg, int cols,
+                                        float* out, hipStream_t stream) {
+    if (!X || !seg || !out || rows <= 0 || nseg <= 0 || cols <= 0) return ARCVAE_ERR_ARG;
+    const size_t lds = (size_t)nseg * 64 * sizeof(float);
+    if (lds > 64 * 1024) return ARCVAE_ERR_ARG;  // nseg <= 256 (vocabulary-sized segment counts)
+    dim3 grid(ceil_div(cols, 64), ceil_div(rows, 256));
+    hipLaunchKernelGGL(segsum_kernel, grid, dim3(256), lds, stream, X, seg, rows, nseg, cols, out);
+    return arcvae_launch_status();
+}
+
+extern "C" int arcvae_transpose_tokens(const int32_t* src, int32_t* dst, int B, int T, hipStream_t stream) {
+    if (!src || !dst || B <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(transpose_tokens_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, stream, src, dst, B, T);
+    return arcvae_launch_status();
+}
+
+// Reference: trainer.py:320,324 (optimizer.update) with MLX optim.Adam defaults (Q7).
+extern "C" int arcvae_adam_update(float* params, const float* grads, float* m, float* v, long n,
+                                  double lr, double beta1, double beta2, double eps, hipStream_t stream) {
+    if (!params || !grads || !m || !v || n <= 0) return ARCVAE_ERR_ARG;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
+                         reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v);
+    const long n4 = (al & 15) ? 0 : n / 4;
+    // (1 - beta) is formed in double and rounded once to f32, as a Python float times an f32 array is.
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    const long work = n4 > 0 ? n4 : n;
+    const int blocks = (int)min((long)2048, (work + 255) / 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, m, v, n4, n, (float)lr,
+                       (float)beta1, (float)beta2, omb1, omb2, (float)eps);
+    return arcvae_launch_status();
+}
+
+extern "C" int arcvae_scale_inplace(float* x, long n, float s, hipStream_t stream) {
+    if (!x || n <= 0) return ARCVAE_ERR_ARG;
+    const int blocks = (int)min((long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, stream, x, n, s);
+    return arcvae_launch_status();
+}
+
+extern "C" int arcvae_abi_version(int* arch_gfx950) {
+    if (arch_gfx950) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        *arch_gfx950 = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            const char* a = prop.gcnArchName;
+            *arch_gfx950 = (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+        }
+    }
+    return 1000;
+}

@@ -1,0 +1,27 @@
+// Internal host-side declarations shared between the translation units of libarcvae_hip.so.
+// The public C ABI is include/arcvae_hip.h; everything here is also extern "C" so the
+// symbols are the same ones the header declares.
+#pragma once
+#include "common.h"
+
+#define ARCVAE_GEMM_ACCUMULATE 1
+#define ARCVAE_GEMM_TANH 2
+#define ARCVAE_GEMM_SPLITK 4
+#define ARCVAE_GEMM_NO_SKINNY 8
+
+extern "C" {
+int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                    const float* B, int ldb, float* C, int ldc, const float* bias, int flags,
+                    hipStream_t stream);
+// out[c] += scale * sum_r X[r*ld + c]
+int arcvae_colsum_accum(const float* X, int rows, int cols, int ld, float* out, float scale,
+                        hipStream_t stream);
+// dst_i[c*rows_i + r] = src_i[r*cols_i + c] for i < n (n <= 16); pointer arrays are HOST arrays.
+int arcvae_transpose_batched(const float* const* src, float* const* dst, const int* rows,
+                             const int* cols, int n, hipStream_t stream);
+// out[seg[r], :] += X[r, :]   (out is [nseg, cols], pre-initialised by the caller)
+int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int rows, int nseg, int cols,
+                             float* out, hipStream_t stream);
+// dst[t*B + b] = src[b*T + t]
+int arcvae_transpose_tokens(const int32_t* src, int32_t* dst, int B, int T, hipStream_t stream);
+}
