@@ -1,0 +1,339 @@
+"""Host-side driver of the HIP kernels: one training step of the AR-CVAE SELFIES path.
+
+Reference path: trainer.py:303-333 -> complete_vae_loss.py:37-99 ->
+models/encoder.py:76-155, models/decoder.py:113-190, losses/{recon,kl,info}.py, then two
+MLX Adam updates.  Here the same step is a fixed sequence of launches on two HIP streams:
+
+  main stream : tokens^T -> table0 GEMM -> LSTM wavefront sweep -> heads -> [stats seam]
+                -> latent loss -> heads bwd -> BPTT wavefront -> weight-grad GEMMs -> Adam(enc)
+  side stream : dense decoder fwd (B*V rows) -> TF walk + CE -> dlogits -> dense decoder bwd
+                -> Adam(dec)
+
+The decoder never reads z, so the two streams only meet at the loss scalars.  The
+whole single-GPU step is captured once per (B,T) shape into a hipGraph and replayed; inputs,
+teacher-forcing coins and the epoch-scheduled hyper-parameters live in static device buffers.
+
+Nothing here computes on the CPU and nothing falls back to PyTorch ops for the math: torch is
+used for device memory, streams, graphs and (in dp.py) torch.distributed/RCCL.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, ptr_array, stream_ptr
+from .store import ParamStore
+
+SCALAR_KEYS = ("total_loss", "recon_loss", "kl_loss", "weighted_kl", "collapse_penalty", "prop_loss",
+               "weighted_prop_loss", "mutual_info", "mi_penalty")
+
+
+@dataclasses.dataclass(frozen=True)
+class ModelDims:
+    V: int
+    E: int
+    H: int
+    Z: int
+    C: int
+    L: int
+
+    def validate(self) -> None:
+        if self.H % 64 != 0:
+            raise ValueError("hidden_dim must be a multiple of 64 for the gfx950 LSTM kernels")
+        if not (1 <= self.L <= 8):
+            raise ValueError("num_layers must be in [1, 8]")
+        if not (1 <= self.C <= 8):
+            raise ValueError("num_conditions must be in [1, 8]")
+        if not (2 <= self.V <= 127):
+            raise ValueError("vocab_size must be in [2, 127]")
+
+
+class Workspace:
+    """Static device buffers for one (B, T) shape."""
+
+    def __init__(self, d: ModelDims, B: int, T: int, device, train: bool = True):
+        f32 = dict(dtype=torch.float32, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        V, E, H, Z, Cc, L = d.V, d.E, d.H, d.Z, d.C, d.L
+        G, BV = 4 * H, B * V
+        self.B, self.T = B, T
+        # inputs
+        self.x = torch.zeros(B, T, **i32)
+        self.x_tb = torch.zeros(T, B, **i32)
+        self.coins = torch.ones(T, dtype=torch.uint8, device=device)
+        self.cond = torch.zeros(B, Cc, **f32)
+        self._hyper_vals = None
+        self.eps = torch.zeros(B, Z, **f32)
+        self.hyper = torch.zeros(8, **f32)
+        # encoder forward
+        self.table0 = torch.empty(V, G, **f32)
+        self.hseq = torch.empty(L, T, B, H, **f32)
+        self.cseq = torch.empty(L, T, B, H, **f32)
+        self.gseq = torch.empty(L, T, B, G, **f32)
+        self.comb = torch.empty(B, 2 * H, **f32)
+        self.lh = torch.empty(B, 2 * H, **f32)
+        self.mu_raw = torch.empty(B, Z, **f32)
+        self.lv_raw = torch.empty(B, Z, **f32)
+        self.mu = torch.empty(B, Z, **f32)
+        self.logvar = torch.empty(B, Z, **f32)
+        self.z = torch.empty(B, Z, **f32)
+        self.stats = torch.zeros(2 * Z + 4, **f32)
+        self.scalars = torch.zeros(16, **f32)
+        # decoder forward (dense over B*V rows)
+        self.tableD = torch.empty(V, G, **f32)
+        self.hact = torch.empty(L, BV, H, **f32)
+        self.gpre = torch.empty(max(L - 1, 1), BV, G, **f32)
+        self.logits = torch.empty(BV, V, **f32)
+        self.lse = torch.empty(BV, **f32)
+        self.nxt = torch.zeros(BV, **i32)
+        self.fed = torch.zeros(B, T, **i32)
+        self.rowloss = torch.zeros(B, **f32)
+        if train:
+            self.dmu_raw = torch.empty(B, Z, **f32)
+            self.dlv_raw = torch.empty(B, Z, **f32)
+            self.dlh = torch.empty(B, 2 * H, **f32)
+            self.dcomb = torch.empty(B, 2 * H, **f32)
+            self.dG = torch.empty(L, T, B, G, **f32)
+            self.dcs = torch.empty(L, T, B, H, **f32)
+            self.wT = torch.empty(2 * L - 1, H, G, **f32)
+            self.dtable0 = torch.empty(V, G, **f32)
+            self.dlogits = torch.empty(BV, V, **f32)
+            self.ddh = torch.empty(2, BV, H, **f32)
+            self.ddG = torch.empty(BV, G, **f32)
+            self.dtableD = torch.empty(V, G, **f32)
+            self.wcpart = torch.empty(V, G, max(Cc, 1), **f32)
+
+
+def _layer_ptrs(store: ParamStore, L: int, leaf: str, grad: bool = False, skip0: bool = False):
+    get = store.g if grad else store.p
+    ts = [None if (skip0 and l == 0) else get(f"lstm_layer_{l}.{leaf}") for l in range(L)]
+    return ptr_array(ts)
+
+
+# --------------------------------------------------------------------------------------------
+# op-level drivers (each is a handful of C-ABI calls on the current stream)
+# --------------------------------------------------------------------------------------------
+def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: float) -> None:
+    """models/encoder.py:76-153 + per-rank latent statistics."""
+    B, T = ws.B, ws.T
+    G = 4 * d.H
+    s = stream_ptr()
+    call("arcvae_transpose_tokens", ptr(ws.x), ptr(ws.x_tb), B, T, s)
+    # table0 = embedding . Wx_0^T + bias_0   ([V,4H]; the layer-0 input projection of every token)
+    call("arcvae_gemm_f32", 0, 1, d.V, G, d.E, ptr(enc.p("embedding.weight")), d.E,
+         ptr(enc.p("lstm_layer_0.Wx")), d.E, ptr(ws.table0), G, ptr(enc.p("lstm_layer_0.bias")), 0, s)
+    wx, _k1 = _layer_ptrs(enc, d.L, "Wx", skip0=True)
+    wh, _k2 = _layer_ptrs(enc, d.L, "Wh")
+    bs, _k3 = _layer_ptrs(enc, d.L, "bias", skip0=True)
+    call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.cseq),
+         ptr(ws.gseq), B, T, d.V, d.H, d.L, s)
+    hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
+    call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
+         ptr(enc.p("condition_fc.bias")), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
+         ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar_hidden.bias")),
+         ptr(enc.p("fc_logvar.weight")), ptr(enc.p("fc_logvar.bias")), ptr(ws.eps), ptr(ws.comb), ptr(ws.lh),
+         ptr(ws.mu_raw), ptr(ws.lv_raw), ptr(ws.mu), ptr(ws.logvar), ptr(ws.z), ptr(ws.stats), B, d.H, d.Z,
+         d.C, float(free_bits), s)
+
+
+def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: int = 0,
+                          temperature: float = 1.0) -> None:
+    """models/decoder.py:152-175 for all B*V (row, token) pairs."""
+    wx, _k1 = _layer_ptrs(dec, d.L, "Wx")
+    bs, _k2 = _layer_ptrs(dec, d.L, "bias")
+    call("arcvae_dec_forward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
+         ptr(dec.p("fc_out.bias")), ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.logits),
+         ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode, float(temperature), stream_ptr())
+
+
+def decoder_chain(ws: Workspace, d: ModelDims) -> None:
+    """models/decoder.py:146-185 walk + losses/recon.py row sums."""
+    call("arcvae_dec_chain_ce", ptr(ws.x), ptr(ws.coins), ptr(ws.nxt), ptr(ws.lse), ptr(ws.logits), ptr(ws.fed),
+         ptr(ws.rowloss), ws.B, ws.T, d.V, stream_ptr())
+
+
+def decoder_backward(dec: ParamStore, ws: Workspace, d: ModelDims, inv_count: float) -> None:
+    s = stream_ptr()
+    call("arcvae_dec_ce_backward", ptr(ws.x), ptr(ws.fed), ptr(ws.logits), ptr(ws.lse), ptr(ws.dlogits), ws.B,
+         ws.T, d.V, float(inv_count), s)
+    wx, _k1 = _layer_ptrs(dec, d.L, "Wx")
+    bs, _k2 = _layer_ptrs(dec, d.L, "bias")
+    dwx, _k3 = _layer_ptrs(dec, d.L, "Wx", grad=True)
+    dbs, _k4 = _layer_ptrs(dec, d.L, "bias", grad=True)
+    call("arcvae_dec_backward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
+         ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.dlogits), ptr(ws.ddh), ptr(ws.ddG),
+         ptr(ws.dtableD), ptr(ws.wcpart), ptr(dec.g("embedding.weight")), dwx, dbs, ptr(dec.g("fc_out.weight")),
+         ptr(dec.g("fc_out.bias")), ws.B, d.V, d.E, d.C, d.H, d.L, s)
+
+
+def latent_loss(ws: Workspace, d: ModelDims, free_bits: float, with_grads: bool) -> None:
+    """complete_vae_loss.py:45-99 from the (global) stats; optionally d/d(mu_raw, lv_raw)."""
+    call("arcvae_latent_loss", ptr(ws.stats), ptr(ws.hyper), ptr(ws.mu), ptr(ws.logvar), ptr(ws.scalars),
+         ptr(ws.dmu_raw) if with_grads else C.c_void_p(0), ptr(ws.dlv_raw) if with_grads else C.c_void_p(0),
+         ws.B, d.Z, ws.T, float(free_bits), stream_ptr())
+
+
+def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims) -> None:
+    B, T = ws.B, ws.T
+    s = stream_ptr()
+    call("arcvae_enc_heads_backward", ptr(ws.cond), ptr(enc.p("fc_mu.weight")),
+         ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar.weight")), ptr(ws.comb), ptr(ws.lh),
+         ptr(ws.dmu_raw), ptr(ws.dlv_raw), ptr(ws.dlh), ptr(ws.dcomb), ptr(enc.g("condition_fc.weight")),
+         ptr(enc.g("condition_fc.bias")), ptr(enc.g("fc_mu.weight")), ptr(enc.g("fc_mu.bias")),
+         ptr(enc.g("fc_logvar_hidden.weight")), ptr(enc.g("fc_logvar_hidden.bias")),
+         ptr(enc.g("fc_logvar.weight")), ptr(enc.g("fc_logvar.bias")), B, d.H, d.Z, d.C, s)
+    wx, _k1 = _layer_ptrs(enc, d.L, "Wx", skip0=True)
+    wh, _k2 = _layer_ptrs(enc, d.L, "Wh")
+    # d/d(hT) = dcomb[:, :H]  (row stride 2H)
+    call("arcvae_enc_lstm_backward", wx, wh, ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG),
+         ptr(ws.dcs), ptr(ws.wT), B, T, d.H, d.L, s)
+    dwx, _k3 = _layer_ptrs(enc, d.L, "Wx", grad=True)
+    dwh, _k4 = _layer_ptrs(enc, d.L, "Wh", grad=True)
+    dbs, _k5 = _layer_ptrs(enc, d.L, "bias", grad=True)
+    call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
+         ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(enc.g("embedding.weight")), dwx, dwh, dbs, B, T, d.V,
+         d.E, d.H, d.L, s)
+
+
+def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    """trainer.py:320,324 -> MLX optim.Adam (no bias correction, Q7) over the module's flat buffer."""
+    call("arcvae_adam_update", ptr(store.flat), ptr(store.grad), ptr(store.adam_m), ptr(store.adam_v),
+         C.c_long(store.numel_padded), float(lr), float(b1), float(b2), float(eps), stream_ptr())
+
+
+# --------------------------------------------------------------------------------------------
+class StepEngine:
+    """Owns workspaces, the side stream and the captured step graph for one (encoder, decoder) pair."""
+
+    def __init__(self, enc: ParamStore, dec: ParamStore, dims: ModelDims):
+        dims.validate()
+        _lib.load()  # fail loudly when the extension is missing
+        self.enc, self.dec, self.d = enc, dec, dims
+        self.device = enc.device
+        self._ws: Dict[Tuple[int, int, bool], Workspace] = {}
+        self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
+        self.side = torch.cuda.Stream(device=self.device)
+        self.hyper_host = dict(beta=0.4, lambda_collapse=0.01, lambda_mi=0.0, target_mi=4.85, free_bits=0.5)
+        self.use_graph = True
+
+    # ---- buffers ----------------------------------------------------------------------------
+    def workspace(self, B: int, T: int, train: bool = True) -> Workspace:
+        key = (B, T, train)
+        if key not in self._ws:
+            if (B, T, True) in self._ws:  # a training workspace also serves forward-only calls
+                return self._ws[(B, T, True)]
+            self._ws[key] = Workspace(self.d, B, T, self.device, train)
+        return self._ws[key]
+
+    def set_hyper(self, ws: Workspace, **kw) -> None:
+        h = dict(self.hyper_host)
+        h.update(kw)
+        self.hyper_host = h
+        vals = (h["beta"], h["lambda_collapse"], h["lambda_mi"], h["target_mi"], h["free_bits"])
+        if ws._hyper_vals != vals:  # epoch-scheduled values change rarely: skip the H2D copy otherwise
+            ws.hyper.copy_(torch.tensor(list(vals) + [0.0, 0.0, 0.0], dtype=torch.float32))
+            ws._hyper_vals = vals
+
+    def load_inputs(self, ws: Workspace, x, cond, eps=None, coins=None) -> None:
+        dev = self.device
+        xt = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x)
+        ws.x.copy_(xt.to(device=dev, dtype=torch.int32))
+        if self.d.C:
+            ct = torch.as_tensor(np.asarray(cond) if not isinstance(cond, torch.Tensor) else cond)
+            ws.cond.copy_(ct.to(device=dev, dtype=torch.float32).reshape(ws.B, self.d.C))
+        if eps is not None:
+            et = torch.as_tensor(np.asarray(eps) if not isinstance(eps, torch.Tensor) else eps)
+            ws.eps.copy_(et.to(device=dev, dtype=torch.float32))
+        if coins is not None:
+            ck = torch.as_tensor(np.asarray(coins).astype(np.uint8))
+            ws.coins.copy_(ck.to(dev))
+
+    # ---- launch sequences -----------------------------------------------------------------------
+    def _enqueue_forward(self, ws: Workspace, free_bits: float) -> None:
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            decoder_forward_dense(self.dec, ws, self.d)
+            decoder_chain(ws, self.d)
+        encoder_forward(self.enc, ws, self.d, free_bits)
+
+    def _enqueue_loss(self, ws: Workspace, free_bits: float, with_grads: bool) -> None:
+        call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z, stream_ptr())
+        latent_loss(ws, self.d, free_bits, with_grads)
+
+    def _enqueue_step(self, ws: Workspace, lr: float, free_bits: float, global_rows: int, update: bool) -> None:
+        """Whole single-process step on (current stream, side stream)."""
+        main = torch.cuda.current_stream()
+        self.enc.grad.zero_()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self.dec.grad.zero_()
+            decoder_forward_dense(self.dec, ws, self.d)
+            decoder_chain(ws, self.d)
+            ev_chain = torch.cuda.Event()
+            ev_chain.record(self.side)
+            decoder_backward(self.dec, ws, self.d, 1.0 / (global_rows * ws.T))
+            if update:
+                adam_update(self.dec, lr)
+        encoder_forward(self.enc, ws, self.d, free_bits)
+        main.wait_event(ev_chain)
+        self._enqueue_loss(ws, free_bits, True)
+        encoder_backward(self.enc, ws, self.d)
+        if update:
+            adam_update(self.enc, lr)
+        main.wait_stream(self.side)
+
+    # ---- public API --------------------------------------------------------------------------------
+    def forward_loss(self, x, cond, eps, coins, **hyper) -> Dict[str, torch.Tensor]:
+        """complete_vae_loss forward only (validation / logging path)."""
+        B, T = int(x.shape[0]), int(x.shape[1])
+        ws = self.workspace(B, T, train=False)
+        self.set_hyper(ws, **hyper)
+        self.load_inputs(ws, x, cond, eps, coins)
+        fb = self.hyper_host["free_bits"]
+        self._enqueue_forward(ws, fb)
+        torch.cuda.current_stream().wait_stream(self.side)
+        self._enqueue_loss(ws, fb, False)
+        return self._results(ws)
+
+    def train_step(self, x, cond, eps, coins, lr: float, update: bool = True, **hyper) -> Dict[str, torch.Tensor]:
+        """loss + grads (+ Adam) for one minibatch; single process (see dp.py for N ranks)."""
+        B, T = int(x.shape[0]), int(x.shape[1])
+        ws = self.workspace(B, T, train=True)
+        self.set_hyper(ws, **hyper)
+        self.load_inputs(ws, x, cond, eps, coins)
+        self.run_step(ws, lr, update)
+        return self._results(ws)
+
+    def run_step(self, ws: Workspace, lr: float, update: bool = True) -> None:
+        """Enqueue (or replay) the step on the current stream; inputs/hyper already in `ws`."""
+        fb = float(self.hyper_host["free_bits"])
+        key = (ws.B, ws.T, float(lr), fb, bool(update))
+        if not self.use_graph:
+            self._enqueue_step(ws, lr, fb, ws.B, update)
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            # warm-up once eagerly (module load, allocator), then capture
+            self._enqueue_step(ws, lr, fb, ws.B, False)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue_step(ws, lr, fb, ws.B, update)
+            self._graphs[key] = g
+        g.replay()
+
+    def _results(self, ws: Workspace) -> Dict[str, torch.Tensor]:
+        out = {k: ws.scalars[i] for i, k in enumerate(SCALAR_KEYS)}
+        out["mu"], out["logvar"], out["z"] = ws.mu, ws.logvar, ws.z
+        return out
+
+    def gather_logits(self, ws: Workspace) -> torch.Tensor:
+        out = torch.empty(ws.B, ws.T, self.d.V, dtype=torch.float32, device=self.device)
+        call("arcvae_dec_gather_logits", ptr(ws.logits), ptr(ws.fed), ptr(out), ws.B, ws.T, self.d.V, stream_ptr())
+        return out

@@ -1,0 +1,115 @@
+"""GPU parity tests of the individual C-ABI ops against plain float64 references."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5  # f32 accumulation noise on contractions up to K ~ 8k; parity bar is 1e-4
+
+
+def _dev(a):
+    return torch.tensor(a, dtype=torch.float32, device="cuda")
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K,flags", [
+    (0, 1, 80, 1024, 128, 0),          # table0: emb . Wx0^T  (skinny, NT)
+    (0, 1, 64, 512, 512, 2),           # heads: tanh(comb . Wlh^T + b) (skinny)
+    (0, 0, 64, 512, 128, 0),           # heads bwd: dmu_raw . Wmu (skinny, NN)
+    (0, 1, 5120, 1024, 256, 0),        # decoder layer-1 projection (tile 128)
+    (0, 1, 5120, 80, 256, 0),          # fc_out (N = 80)
+    (0, 0, 5120, 256, 1024, 0),        # dh = dG . Wx (NN)
+    (1, 0, 1024, 256, 5120, 1 | 4),    # dWx += dG^T . h (TN, split-K atomics)
+    (1, 0, 80, 256, 5120, 1 | 4),      # dWout
+    (1, 0, 128, 512, 64, 1),           # dWmu (K = B)
+    (0, 1, 80, 1024, 129, 0),          # odd K, unaligned ld (scalar-load path)
+    (0, 1, 37, 53, 19, 0),             # ragged everything
+    (1, 1, 70, 90, 33, 0),             # TT
+    (0, 1, 4, 256, 128, 0),            # tiny batch skinny
+])
+def test_gemm(tA, tB, M, N, K, flags):
+    from arcvae_hip import _lib
+    rs = np.random.RandomState(M * 7 + N * 3 + K)
+    A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    C0 = rs.standard_normal((M, N)).astype(np.float32)
+    use_bias = not (flags & 4)
+    dA, dB, dC, db = _dev(A), _dev(Bm), _dev(C0), _dev(bias)
+    _lib.gemm(bool(tA), bool(tB), M, N, K, dA, A.shape[1], dB, Bm.shape[1], dC, N,
+              db if use_bias else None, flags)
+    torch.cuda.synchronize()
+    ref = (A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)
+    if use_bias:
+        ref = ref + bias
+    if flags & 1:
+        ref = ref + C0
+    if flags & 2:
+        ref = np.tanh(ref)
+    assert rel_err(dC.cpu().numpy(), ref) < TOL
+
+
+def test_gemm_strided_c():
+    """C with ldc > N and B with ldb > K (the decoder's Wx0[:, :E] sub-block)."""
+    from arcvae_hip import _lib
+    rs = np.random.RandomState(3)
+    M, N, K, ld = 256, 128, 80, 129
+    A = rs.standard_normal((K, M)).astype(np.float32)   # stored [K,M] (transA)
+    Bm = rs.standard_normal((K, N)).astype(np.float32)
+    C0 = rs.standard_normal((M, ld)).astype(np.float32)
+    dA, dB, dC = _dev(A), _dev(Bm), _dev(C0)
+    _lib.gemm(True, False, M, N, K, dA, M, dB, N, dC, ld, None, 1)
+    torch.cuda.synchronize()
+    ref = C0.astype(np.float64).copy()
+    ref[:, :N] += A.T.astype(np.float64) @ Bm.astype(np.float64)
+    assert rel_err(dC.cpu().numpy(), ref) < TOL
+
+
+def test_adam_matches_mlx_formula():
+    from arcvae_hip import _lib
+    from arcvae_hip._lib import call, ptr, stream_ptr
+    import ctypes as C
+    rs = np.random.RandomState(0)
+    n = 1000 + 3
+    p = rs.standard_normal(n).astype(np.float32)
+    g = (rs.standard_normal(n) * 1e-2).astype(np.float32)
+    g[::7] = 0.0  # dead parameters must stay bit-identical (Q7)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    dp, dg, dm, dv = _dev(p), _dev(g), _dev(m), _dev(v)
+    for _ in range(3):
+        call("arcvae_adam_update", ptr(dp), ptr(dg), ptr(dm), ptr(dv), C.c_long(n), 2e-4, 0.9, 0.999, 1e-8,
+             stream_ptr())
+    torch.cuda.synchronize()
+    pp, mm, vv = p.copy(), m.copy(), v.copy()
+    f = np.float32
+    for _ in range(3):
+        mm = f(0.9) * mm + f(1 - 0.9) * g
+        vv = f(0.999) * vv + f(1 - 0.999) * np.square(g)
+        pp = pp - f(2e-4) * mm / (np.sqrt(vv) + f(1e-8))
+    out = dp.cpu().numpy()
+    assert np.array_equal(out[::7], p[::7])
+    assert rel_err(out, pp) < 1e-6
+    assert rel_err(dm.cpu().numpy(), mm) < 1e-6
+    # step-1 identity from SURVEY section 4: update = lr*0.1g / (sqrt(0.001) |g| + 1e-8)
+
+
+def test_segsum_and_colsum():
+    from arcvae_hip._lib import call, ptr, stream_ptr
+    rs = np.random.RandomState(1)
+    R, S, Cc = 1000, 80, 200
+    X = rs.standard_normal((R, Cc)).astype(np.float32)
+    seg = rs.randint(0, S, size=R).astype(np.int32)
+    dX = _dev(X)
+    dseg = torch.tensor(seg, dtype=torch.int32, device="cuda")
+    out = torch.zeros(S, Cc, device="cuda")
+    call("arcvae_segsum_rows_accum", ptr(dX), ptr(dseg), R, S, Cc, ptr(out), stream_ptr())
+    cs = torch.zeros(Cc, device="cuda")
+    call("arcvae_colsum_accum", ptr(dX), R, Cc, Cc, ptr(cs), 1.0, stream_ptr())
+    torch.cuda.synchronize()
+    ref = np.zeros((S, Cc))
+    np.add.at(ref, seg, X.astype(np.float64))
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+    assert rel_err(cs.cpu().numpy(), X.astype(np.float64).sum(0)) < TOL
