@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SELFIES sequences/sec of the AR-CVAE training step on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one minibatch of synthetic SELFIES-shaped input:
+encoder LSTM sweep + heads, dense decoder, ELBO-style loss, hand-written backward, two Adam
+updates (BASELINE.json configs[1]: default AR-CVAE V80 E128 H256 Z128 C1 L2, bs 64, T 128).
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, each with its
+own 64-row shard (weak scaling), stats + gradient all-reduce over RCCL.
+
+One JSON line is printed by rank 0 with `roofline` (dominant kernel, live HIP-event timing) and
+`cpu_baseline` (the oracle = CPU restatement of the reference step, timed on this box's host
+cores; the MLX-CPU reference itself cannot run offline -- BASELINE.md section 2).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mlx-vae_amd"))
+
+# default AR-CVAE (reference train.py:25-30) at BASELINE.json configs[1]
+V, EMB, H, Z, C, L = 80, 128, 256, 128, 1, 2
+T = 128
+HYPER = dict(beta=0.0, lambda_collapse=0.001, lambda_mi=0.01, target_mi=4.85, free_bits=1.0)  # epoch-0 schedule
+LR = 2e-4
+TF_RATIO = 0.9
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def fwd_flops_per_seq(V, E, H, Z, C, L, T):
+    """SURVEY.md section 8(d) algorithmic forward FLOPs per sequence."""
+    enc_in = T * (2 * E * 4 * H + (L - 1) * 2 * H * 4 * H)
+    enc_rec = (T - 1) * L * 2 * H * 4 * H
+    heads = 2 * C * H + 2 * (2 * H) * Z + 2 * (2 * H) * (2 * H) + 2 * (2 * H) * Z
+    dec = T * (2 * (E + C) * 4 * H + (L - 1) * 2 * H * 4 * H + 2 * H * V)
+    return enc_in + enc_rec + heads + dec
+
+
+def synth(rs, B):
+    lengths = rs.randint(20, T - 1, size=B)
+    x = np.zeros((B, T), dtype=np.int32)
+    for b in range(B):
+        n = int(lengths[b])
+        x[b, :n] = rs.randint(3, V, size=n)
+        x[b, n] = 2
+    cond = rs.standard_normal((B, C)).astype(np.float32)
+    return x, cond
+
+
+def host_cores() -> int:
+    """Cores this process may actually use (affinity mask and cgroup quota), not the machine total."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))  # a one-GPU box's CPU share is 16
+
+
+def log(msg: str) -> None:
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sample_steps: int):
+    """Time the oracle (CPU restatement of the reference step) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import arcvae_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = O.Config(V, EMB, H, Z, C, L)
+    params = O.init_params(cfg, 1234)
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v = {k: np.zeros_like(vv) for k, vv in params.items()}
+    x, cond = O.synthetic_batch(cfg, 64, T, 67)
+    eps = np.random.RandomState(4321).standard_normal((64, Z)).astype(np.float32)
+    rs = np.random.RandomState(68)
+    hy = dict(beta=HYPER["beta"], lambda_collapse=HYPER["lambda_collapse"], lambda_mi=HYPER["lambda_mi"],
+              free_bits=HYPER["free_bits"], target_mi=HYPER["target_mi"])
+    O.train_step(params, m, v, cfg, x, cond, eps, O.draw_coins(rs, T, TF_RATIO), LR, **hy)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        O.train_step(params, m, v, cfg, x, cond, eps, O.draw_coins(rs, T, TF_RATIO), LR, **hy)
+    dt = time.perf_counter() - t0
+    return dict(value=64 * sample_steps / dt, unit="sequences/s", cores=cores, kind="port",
+                sample=f"{sample_steps} training steps of the default config (bs 64, T 128) with the torch-CPU "
+                       f"oracle, {dt:.1f} s; MLX-CPU itself is not installable offline")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from arcvae_hip import _lib
+    from arcvae_hip import engine as E
+    from arcvae_hip.dp import DataParallelStep, EngineOps
+    from arcvae_hip.store import ParamStore, decoder_shapes, encoder_shapes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    _lib.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch_per_gpu
+    dims = E.ModelDims(V=V, E=EMB, H=H, Z=Z, C=C, L=L)
+    gen = torch.Generator().manual_seed(1234)  # identical initial weights on every rank
+    enc = ParamStore(encoder_shapes(V, EMB, H, Z, C, L), dev)
+    dec = ParamStore(decoder_shapes(V, EMB, H, Z, C, L), dev)
+    enc.init_mlx_like(H, gen)
+    dec.init_mlx_like(H, gen)
+    enc.p("fc_logvar.bias").fill_(0.35)
+    eng = E.StepEngine(enc, dec, dims)
+    eng.use_graph = not args.no_graph
+    ws = eng.workspace(B, T, train=True)
+    eng.set_hyper(ws, **HYPER)
+
+    # device-resident synthetic batches (per-rank shard) and per-step coins (same on every rank, Q5)
+    rs = np.random.RandomState(67 + rank)
+    nbuf = 8
+    xs, cs, es = [], [], []
+    for _ in range(nbuf):
+        x, cond = synth(rs, B)
+        xs.append(torch.tensor(x, device=dev))
+        cs.append(torch.tensor(cond, device=dev))
+        es.append(torch.tensor(rs.standard_normal((B, Z)).astype(np.float32), device=dev))
+    crs = np.random.RandomState(4242)
+    total = args.warmup + args.steps
+    coins = torch.tensor((crs.rand(total, T) < TF_RATIO).astype(np.uint8), device=dev)
+
+    dp = None
+    if world > 1:
+        dp = DataParallelStep(EngineOps(eng, ws, LR, B * world, use_graph=eng.use_graph))
+
+    def one_step(i):
+        k = i % nbuf
+        ws.x.copy_(xs[k], non_blocking=True)
+        ws.cond.copy_(cs[k], non_blocking=True)
+        ws.eps.copy_(es[k], non_blocking=True)
+        ws.coins.copy_(coins[i], non_blocking=True)
+        if dp is None:
+            eng.run_step(ws, LR, update=True)
+        else:
+            dp.step()
+
+    log(f"rank {rank}/{world}: warm-up ({args.warmup} steps, graph={eng.use_graph})")
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    log("timing")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    scal = ws.scalars.cpu().numpy()
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        seqs = B * world * args.steps / dt
+        f_seq = 3 * fwd_flops_per_seq(V, EMB, H, Z, C, L, T)
+        out = {
+            "metric": "SELFIES sequences/sec (whole node), AR-CVAE training step",
+            "value": seqs, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "default AR-CVAE V80 E128 H256 Z128 C1 L2, bs 64/GPU, T 128, tf 0.9, "
+                                   "beta 0 (epoch-0 schedule), fwd+bwd+Adam (BASELINE.json configs[1])",
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "hip_graph": bool(eng.use_graph)},
+            "elbo": {"total": float(scal[0]), "recon": float(scal[1]), "kl": float(scal[2]),
+                     "mutual_info": float(scal[7])},
+            "step_tflops_algorithmic": seqs * f_seq / 1e12,
+            "step_frac_of_f32_mfma_peak": seqs * f_seq / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+        }
+        log(f"timed: {ms:.3f} ms/step, {seqs:.0f} seq/s")
+        if not args.no_roofline:
+            out["roofline"] = roofline_probe(eng, ws, torch)
+            log("roofline probe done")
+        if args.cpu_steps > 0:
+            log(f"cpu baseline on {host_cores()} host cores")
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_probe(eng, ws, torch):
+    """Live HIP-event timing of the dominant kernel on the stream it is launched on.
+
+    Dominant kernel (by summed device time, profiles/): lstm_bwd_step_kernel, the BPTT wavefront
+    step.  Algorithmic FLOPs per launch (steady state, both layers in flight at the default shape):
+    layer 1: dG_1[t+1] . Wh_1 (2*B*4H*H); layer 0: dG_1[t] . Wx_1 + dG_0[t+1] . Wh_0 (2 * 2*B*4H*H).
+    It is timed as the whole arcvae_enc_lstm_backward call (T+L-1 dependent launches + one weight
+    transpose) between two events, divided by the launch count, so the figure includes the
+    launch-boundary gaps of the dependent chain -- which is what bounds this path.
+    """
+    from arcvae_hip import engine as E
+    d = eng.d
+    B, Tn = ws.B, ws.T
+    wx, _k1 = E._layer_ptrs(eng.enc, d.L, "Wx", skip0=True)
+    wh, _k2 = E._layer_ptrs(eng.enc, d.L, "Wh")
+    s = torch.cuda.current_stream()
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def sweep():
+        E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * d.H,
+               E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.wT), B, Tn, d.H, d.L, E.stream_ptr())
+
+    g = torch.cuda.CUDAGraph()
+    sweep()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        sweep()
+    g.replay()
+    torch.cuda.synchronize()
+    e0.record(s)
+    for _ in range(reps):
+        g.replay()
+    e1.record(s)
+    torch.cuda.synchronize()
+    launches = Tn + d.L - 1
+    us = 1e3 * e0.elapsed_time(e1) / reps / launches
+    jobs = d.L * Tn
+    flops_total = 2.0 * B * 4 * d.H * d.H * (jobs - d.L + (d.L - 1) * Tn)  # Wh terms (t<T-1) + Wx_up terms
+    flops_per_launch = flops_total / launches
+    ach = flops_per_launch / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "lstm_bwd_step_kernel", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "us_per_launch": us, "launches_per_sweep": launches,
+            "note": "f32-input MFMA peak; per-launch time includes the dependent-launch gap (chain-latency bound)"}
+
+
+if __name__ == "__main__":
+    main()

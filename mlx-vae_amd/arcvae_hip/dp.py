@@ -1,0 +1,177 @@
+"""Data-parallel training step: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference is single-process (no collective anywhere), so this layer is
+defined by equivalence: N ranks x local minibatch == one process x the concatenated minibatch.
+Batch rows are independent everywhere except the loss's batch statistics, so a
+step needs exactly two exchanges:
+
+  1. forward seam : all-reduce(SUM) of `stats` (2Z+4 floats: sum mu, sum exp(logvar), KL sums,
+                    row count, CE row-sum) -> every rank evaluates the GLOBAL loss scalars and
+                    the MI gate, and differentiates them w.r.t. its LOCAL rows (1/B_global scaling);
+  2. backward     : all-reduce(SUM) of the flat gradient buffers, one bucket per module.  The
+                    decoder never reads z (Q2), so its whole forward+backward runs on the side
+                    stream and its bucket (3.9 MB) is reduced while the encoder BPTT sweep is still
+                    running on the main stream; the encoder bucket (5.3 MB) is the exposed tail.
+                    Messages are <= 5.3 MB: on point-to-point xGMI RCCL picks a direct
+                    reduce-scatter/all-gather rather than a per-link-bound ring.
+
+Teacher-forcing coins, weights and Adam state must be identical on all ranks (same seed / same
+reduced gradients); `DataParallelStep` never touches them.
+
+The control flow is written against a small `ops` protocol so that the same code is exercised by
+the CPU/gloo tests (tests/test_dp_gloo.py, where `ops` is backed by the test oracle) and by the
+HIP engine (`EngineOps`) on the GPU.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import ContextManager, List, Optional, Protocol
+
+import torch
+import torch.distributed as dist
+
+
+class StepOps(Protocol):
+    stats: torch.Tensor
+
+    def forward_local(self) -> None: ...      # fills self.stats with this rank's partial sums
+    def backward_local(self) -> None: ...     # self.stats now holds GLOBAL sums; fills all gradients
+    def early_buckets(self) -> List[torch.Tensor]: ...  # gradients ready before backward_local completes
+    def late_buckets(self) -> List[torch.Tensor]: ...   # gradients ready after backward_local
+    def early_context(self) -> ContextManager: ...      # stream context the early reduce is issued from
+    def apply_update(self) -> None: ...
+
+
+class DataParallelStep:
+    def __init__(self, ops: StepOps, group: Optional[dist.ProcessGroup] = None):
+        self.ops = ops
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # exercise the collectives even at world size 1 (single-GPU rehearsal of the N-rank path)
+        self.force = os.environ.get("ARCVAE_DP_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+
+    def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
+        if self.world == 1 and not self.force:
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def step(self) -> None:
+        ops = self.ops
+        ops.forward_local()
+        self._all_reduce(ops.stats)
+        ops.backward_local()
+        with ops.early_context():
+            works = [self._all_reduce(g, async_op=True) for g in ops.early_buckets()]
+        for g in ops.late_buckets():
+            self._all_reduce(g)
+        for w in works:
+            if w is not None:
+                w.wait()
+        ops.apply_update()
+
+
+class EngineOps:
+    """StepOps over the HIP StepEngine: per-stream hipGraph segments with the collectives between.
+
+    side stream : [dec_fwd graph] -> ev_chain -> [dec_bwd graph] -> ev_dec_bwd
+    main stream : [enc_fwd graph] -> wait ev_chain -> set_recon -> (all-reduce stats)
+                  -> [enc_bwd graph] -> (all-reduce enc.grad) -> Adam x2
+    comm stream : wait ev_dec_bwd -> (all-reduce dec.grad), overlapping the encoder BPTT
+    """
+
+    def __init__(self, engine, ws, lr: float, global_rows: int, use_graph: bool = True):
+        from . import engine as E
+        self.E = E
+        self.eng, self.ws, self.lr = engine, ws, float(lr)
+        self.global_rows = int(global_rows)
+        self.stats = ws.stats
+        self.use_graph = use_graph
+        self._g = {}
+        self.comm = torch.cuda.Stream(device=engine.device)
+        self._ev_chain = torch.cuda.Event()
+        self._ev_dec_bwd = torch.cuda.Event()
+
+    def _run(self, key: str, fn, stream: torch.cuda.Stream) -> None:
+        """Run `fn` on `stream`; captured once into a hipGraph (a single-stream segment)."""
+        with torch.cuda.stream(stream):
+            if not self.use_graph:
+                fn()
+                return
+            g = self._g.get(key)
+            if g is None:
+                fn()  # first step runs eagerly (its results are this step's results) ...
+                stream.synchronize()
+                try:  # ... and is then recorded for replay from the next step on
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                        fn()
+                    self._g[key] = g
+                except Exception as exc:  # keep training eagerly if capture is refused
+                    print(f"[arcvae_hip.dp] graph capture of segment {key!r} failed ({exc}); running eagerly")
+                    torch.cuda.synchronize()
+                    self._g[key] = False
+                return
+            if g is False:
+                fn()
+            else:
+                g.replay()
+
+    # -- StepOps ------------------------------------------------------------------------------------
+    def forward_local(self) -> None:
+        E, eng, ws, d = self.E, self.eng, self.ws, self.eng.d
+        main = torch.cuda.current_stream()
+        fb = float(eng.hyper_host["free_bits"])
+        eng.side.wait_stream(main)
+
+        def dec_fwd():
+            eng.dec.grad.zero_()
+            E.decoder_forward_dense(eng.dec, ws, d)
+            E.decoder_chain(ws, d)
+
+        def dec_bwd():
+            E.decoder_backward(eng.dec, ws, d, 1.0 / (self.global_rows * ws.T))
+
+        def enc_fwd():
+            eng.enc.grad.zero_()
+            E.encoder_forward(eng.enc, ws, d, fb)
+
+        self._run("dec_fwd", dec_fwd, eng.side)
+        self._ev_chain.record(eng.side)
+        # the decoder backward does not depend on the stats seam: keep the side stream busy
+        self._run("dec_bwd", dec_bwd, eng.side)
+        self._ev_dec_bwd.record(eng.side)
+        self._run("enc_fwd", enc_fwd, main)
+        main.wait_event(self._ev_chain)
+        E.call("arcvae_stats_set_recon", E.ptr(ws.rowloss), ws.B, E.ptr(ws.stats), d.Z, E.stream_ptr())
+
+    def backward_local(self) -> None:
+        E, eng, ws, d = self.E, self.eng, self.ws, self.eng.d
+        fb = float(eng.hyper_host["free_bits"])
+
+        def enc_bwd():
+            E.latent_loss(ws, d, fb, True)
+            E.encoder_backward(eng.enc, ws, d)
+
+        self._run("enc_bwd", enc_bwd, torch.cuda.current_stream())
+
+    @contextlib.contextmanager
+    def early_context(self):
+        # issue the decoder-bucket reduce from the comm stream so it does not queue behind BPTT
+        self.comm.wait_event(self._ev_dec_bwd)
+        with torch.cuda.stream(self.comm):
+            yield
+
+    def early_buckets(self) -> List[torch.Tensor]:
+        return [self.eng.dec.grad]
+
+    def late_buckets(self) -> List[torch.Tensor]:
+        return [self.eng.enc.grad]
+
+    def apply_update(self) -> None:
+        E, eng = self.E, self.eng
+        main = torch.cuda.current_stream()
+        main.wait_stream(eng.side)
+        main.wait_stream(self.comm)
+        E.adam_update(eng.dec, self.lr)
+        E.adam_update(eng.enc, self.lr)

@@ -43,8 +43,8 @@ class ModelDims:
     L: int
 
     def validate(self) -> None:
-        if self.H % 64 != 0:
-            raise ValueError("hidden_dim must be a multiple of 64 for the gfx950 LSTM kernels")
+        if self.H % 64 != 0 or not (64 <= self.H <= 512):
+            raise ValueError("hidden_dim must be a multiple of 64 in [64, 512] for the gfx950 LSTM kernels")
         if not (1 <= self.L <= 8):
             raise ValueError("num_layers must be in [1, 8]")
         if not (1 <= self.C <= 8):

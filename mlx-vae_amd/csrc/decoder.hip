@@ -159,14 +159,19 @@ __global__ __launch_bounds__(256) void dec_l0_bwd_kernel(const float* __restrict
     }
 }
 
-// dWx0[j, E + c] += sum_v wcpart[v, j, c]
-__global__ void dec_wc_reduce_kernel(const float* __restrict__ wcpart, float* dWx0, int V, int G, int E, int C) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// dWx0[j, E + c] += sum_v wcpart[v, j, c]   (one wave per (j,c): lanes stride over v)
+__global__ __launch_bounds__(256) void dec_wc_reduce_kernel(const float* __restrict__ wcpart, float* dWx0, int V,
+                                                            int G, int E, int C) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= G * C) return;
     float s = 0.f;
-    for (int v = 0; v < V; ++v) s += wcpart[(long)v * G * C + idx];
-    const int j = idx / C, c = idx % C;
-    dWx0[(long)j * (E + C) + E + c] += s;
+    for (int v = lane; v < V; v += 64) s += wcpart[(long)v * G * C + idx];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int j = idx / C, c = idx % C;
+        dWx0[(long)j * (E + C) + E + c] += s;
+    }
 }
 
 // ---- per-row statistics of the dense logits: lse and the fed-back token ---------------------
@@ -441,7 +446,7 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
     rc = arcvae_colsum_accum(dtableD, V, G, G, dbias[0], 1.0f, stream);
     if (rc) return rc;
     if (C > 0)
-        hipLaunchKernelGGL(dec_wc_reduce_kernel, dim3(ceil_div(G * C, 256)), dim3(256), 0, stream, wcpart, dWx[0],
+        hipLaunchKernelGGL(dec_wc_reduce_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, stream, wcpart, dWx[0],
                            V, G, E, C);
     // dEmb += dTableD . Wx0[:, :E]        (M=V, N=E, K=4H; B operand = Wx0 [4H, E+C] row-major, ld E+C)
     rc = arcvae_gemm_f32(0, 0, V, E, G, dtableD, G, Wx[0], E + C, dEmb, E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);

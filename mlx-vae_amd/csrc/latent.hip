@@ -41,45 +41,40 @@ __global__ __launch_bounds__(256) void build_comb_kernel(const float* __restrict
 __device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 // mu = 2 tanh(mu_raw/2); logvar = tanh(lv_raw/2) - 1; z = mu + eps*exp(logvar/2); partial stats.
-// Block = 64 rows x all Z columns (threads stride over Z).
+// Block = 4 batch rows (one per wave); lanes stride over Z.  Column sums go to stats with one f32
+// atomic per (row, column) -- B adds per address, a few microseconds at B = 64..2048 -- and the
+// per-row KL sums are wave-reduced first.
 __global__ __launch_bounds__(256) void latent_apply_kernel(const float* __restrict__ mu_raw,
                                                            const float* __restrict__ lv_raw,
                                                            const float* __restrict__ eps, float* mu, float* logvar,
                                                            float* z, float* stats, int B, int Z, float fb_min) {
-    __shared__ float red[2][4];
-    const int r0 = blockIdx.x * 64, r1 = min(B, r0 + 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
     float klmi = 0.f, klfb = 0.f;
-    for (int j = threadIdx.x; j < Z; j += 256) {
-        float smu = 0.f, svar = 0.f;
-        for (int b = r0; b < r1; ++b) {
-            const long i = (long)b * Z + j;
-            const float m = tanhf(mu_raw[i] / 2.0f) * 2.0f;
-            const float lv = tanhf(lv_raw[i] / 2.0f) * 1.0f - 1.0f;
-            mu[i] = m;
-            logvar[i] = lv;
-            z[i] = m + eps[i] * expf(0.5f * lv);
-            const float mc = clipf(m, -3.0f, 3.0f), lc = clipf(lv, -6.0f, 3.0f);
-            const float var = expf(lc);
-            const float k = -0.5f * (1.0f + lc - mc * mc - var);
-            smu += mc;
-            svar += var;
-            klmi += k;
-            float kf = fmaxf(k, 0.0f);
-            if (fb_min > 0.0f) kf = fmaxf(kf, fb_min);
-            klfb += kf;
-        }
-        atomicAdd(stats + j, smu);
-        atomicAdd(stats + Z + j, svar);
+    for (int j = lane; j < Z; j += 64) {
+        const long i = (long)b * Z + j;
+        const float m = tanhf(mu_raw[i] / 2.0f) * 2.0f;
+        const float lv = tanhf(lv_raw[i] / 2.0f) * 1.0f - 1.0f;
+        mu[i] = m;
+        logvar[i] = lv;
+        z[i] = m + eps[i] * expf(0.5f * lv);
+        const float mc = clipf(m, -3.0f, 3.0f), lc = clipf(lv, -6.0f, 3.0f);
+        const float var = expf(lc);
+        const float k = -0.5f * (1.0f + lc - mc * mc - var);
+        atomicAdd(stats + j, mc);
+        atomicAdd(stats + Z + j, var);
+        klmi += k;
+        float kf = fmaxf(k, 0.0f);
+        if (fb_min > 0.0f) kf = fmaxf(kf, fb_min);
+        klfb += kf;
     }
     klmi = wave_sum(klmi);
     klfb = wave_sum(klfb);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = klmi; red[1][wave] = klfb; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(stats + 2 * Z, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-        atomicAdd(stats + 2 * Z + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
-        atomicAdd(stats + 2 * Z + 2, (float)(r1 - r0));
+    if (lane == 0) {
+        atomicAdd(stats + 2 * Z, klmi);
+        atomicAdd(stats + 2 * Z + 1, klfb);
+        atomicAdd(stats + 2 * Z + 2, 1.0f);
     }
 }
 
@@ -207,7 +202,7 @@ extern "C" int arcvae_enc_heads_forward(const float* hT, const float* cond, cons
     if (rc) return rc;
     if (hipMemsetAsync(stats, 0, (size_t)(2 * Z + 4) * sizeof(float), stream) != hipSuccess) return ARCVAE_ERR_LAUNCH;
     const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
-    hipLaunchKernelGGL(latent_apply_kernel, dim3(ceil_div(B, 64)), dim3(256), 0, stream, mu_raw, lv_raw, eps, mu,
+    hipLaunchKernelGGL(latent_apply_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, mu_raw, lv_raw, eps, mu,
                        logvar, z, stats, B, Z, fb_min);
     return arcvae_launch_status();
 }

@@ -12,8 +12,10 @@
 // once per step for the V distinct tokens).
 //
 // Tiles: forward -- 16 batch rows x 4 hidden units (16 gate columns i,f,g,o interleaved so the
-// cell update for a unit is local to the block); backward -- 16 rows x 16 hidden units.  Both
-// split K over the block's 4 waves on v_mfma_f32_16x16x4_f32 (skinny.h).
+// cell update for a unit is local to the block), K split over 4 waves; backward -- 16 rows x 16
+// hidden units, K = 4H (per source) split over 16 waves.  Both on v_mfma_f32_16x16x4_f32 with
+// every operand load issued before the first MFMA (skinny.h): a step kernel has nothing to hide
+// memory latency behind, so the L2/Infinity-Cache round trip must be paid once, not per K-chunk.
 //
 // Layout: time-major activations [L][T][B][*] so that each step's operands are contiguous slabs
 // and "h shifted by one step" (needed by dWh) is a pointer offset.
@@ -23,9 +25,9 @@
 namespace {
 
 struct FwdJob {
-    const float* xin;    // [B,Kin]  h^{l-1}_t, or null for layer 0
-    const float* Wx;     // [4H,Kin]
-    const float* hprev;  // [B,H]    h^l_{t-1}, or null at t == 0 (MLX: hidden=None skips the term)
+    const float* xin;    // [B,H]   h^{l-1}_t, or null for layer 0
+    const float* Wx;     // [4H,H]
+    const float* hprev;  // [B,H]   h^l_{t-1}, or null at t == 0 (MLX: hidden=None skips the term)
     const float* Wh;     // [4H,H]
     const float* pre;    // layer 0: table0 [V,4H] (bias folded in); else bias [4H]
     const int32_t* tok;  // layer 0: tokens of this step [B]; else null
@@ -33,16 +35,17 @@ struct FwdJob {
     float* h;            // [B,H]
     float* c;            // [B,H]
     float* gates;        // [B,4H] post-activation i,f,g,o (saved for BPTT)
-    int Kin;
-    int pad;
 };
 struct FwdArgs {
     FwdJob job[ARCVAE_MAX_LAYERS];
     int B, H, V;
 };
 
+// CH = H / 64: each of the 4 waves owns H/4 = 16*CH floats of K per source.
+template <int CH>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     __shared__ float red[4 * 256];
+    __shared__ float act[256];
     const FwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H;
@@ -50,36 +53,43 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     const int arow = min(r0 + (lane & 15), B - 1);
     const int jc = lane & 15;
     const long wrow = (long)(jc >> 2) * H + u0 + (jc & 3);  // gate-major weight row of tile column jc
+    const bool s1 = j.xin != nullptr, s2 = j.hprev != nullptr;
+    SkinnyFrag<CH> f1, f2;
+    if (s1) skinny_load<CH>(f1, j.xin, (long)arow * H, j.Wx, wrow * H, wave, lane);
+    if (s2) skinny_load<CH>(f2, j.hprev, (long)arow * H, j.Wh, wrow * H, wave, lane);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (j.xin) skinny_accum_kk(acc0, acc1, j.xin, (long)arow * j.Kin, j.Wx, wrow * j.Kin, j.Kin, wave, lane);
-    if (j.hprev) skinny_accum_kk(acc0, acc1, j.hprev, (long)arow * H, j.Wh, wrow * H, H, wave, lane);
-    skinny_store_partial(red, acc0, acc1, wave, lane);
+    if (s1) skinny_mfma<CH>(f1, acc0, acc1);
+    if (s2) skinny_mfma<CH>(f2, acc0, acc1);
+    skinny_store_partial_n(red, acc0, acc1, wave, lane);
     __syncthreads();
-    if (tid < 64) {
-        const int row = tid >> 2, u = tid & 3;
+    {   // one gate activation per thread: (row, col) -> gate = col>>2, unit = u0 + (col&3)
+        const int row = tid >> 4, col = tid & 15;
         const int b = r0 + row;
         if (b < B) {
-            const int unit = u0 + u;
+            const int gcol = (col >> 2) * H + u0 + (col & 3);
             const float* pre = j.pre;
             if (j.tok) {
                 int tk = j.tok[b];
                 tk = min(max(tk, 0), a.V - 1);
                 pre += (long)tk * 4 * H;
             }
-            const float gi = skinny_reduced(red, row, u) + pre[unit];
-            const float gf = skinny_reduced(red, row, 4 + u) + pre[H + unit];
-            const float gg = skinny_reduced(red, row, 8 + u) + pre[2 * H + unit];
-            const float go = skinny_reduced(red, row, 12 + u) + pre[3 * H + unit];
-            const float i = sigmoidf_acc(gi), f = sigmoidf_acc(gf), g = tanhf(gg), o = sigmoidf_acc(go);
-            const long hb = (long)b * H + unit;
+            const float v = skinny_reduced_n<4>(red, row, col) + pre[gcol];
+            const float av = ((col >> 2) == 2) ? tanhf(v) : sigmoidf_acc(v);
+            act[tid] = av;
+            j.gates[(long)b * 4 * H + gcol] = av;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int row = tid >> 2, u = tid & 3;
+        const int b = r0 + row;
+        if (b < B) {
+            const float i = act[row * 16 + u], f = act[row * 16 + 4 + u], g = act[row * 16 + 8 + u],
+                        o = act[row * 16 + 12 + u];
+            const long hb = (long)b * H + u0 + u;
             const float c = j.cprev ? f * j.cprev[hb] + i * g : i * g;
             j.h[hb] = o * tanhf(c);
             j.c[hb] = c;
-            float* gp = j.gates + (long)b * 4 * H + unit;
-            gp[0] = i;
-            gp[H] = f;
-            gp[2 * H] = g;
-            gp[3 * H] = o;
         }
     }
 }
@@ -89,14 +99,14 @@ struct BwdJob {
     const float* WxTup;   // [H,4H] = Wx_{l+1}^T
     const float* dGnext;  // [B,4H] dG^l_{t+1} or null (t == T-1)
     const float* WhT;     // [H,4H] = Wh_l^T
-    const float* dhext;   // [B,H] external gradient (top layer, t == T-1) or null
+    const float* dhext;   // [B,dhext_ld] external gradient (top layer, t == T-1) or null
     const float* gates;   // [B,4H] i,f,g,o at (l,t)
     const float* c;       // [B,H] c_t
     const float* cprev;   // [B,H] c_{t-1} or null (t == 0)
     const float* dcin;    // [B,H] dc_{t+1} * f_{t+1} or null (t == T-1)
     float* dcout;         // [B,H] dc_t * f_t
     float* dG;            // [B,4H] pre-activation gate gradients
-    int dhext_ld;         // row stride of dhext
+    int dhext_ld;
     int pad;
 };
 struct BwdArgs {
@@ -104,43 +114,87 @@ struct BwdArgs {
     int B, H;
 };
 
-__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(BwdArgs a) {
-    __shared__ float red[4 * 256];
+// 16 waves: wave w owns 4H/16 = 16*CH floats of the contraction index per source.
+template <int CH>
+__global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
+    __shared__ float red[16 * 256];
     const BwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
     const int r0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
     const int arow = min(r0 + (lane & 15), B - 1);
     const long wrow = u0 + (lane & 15);
+    const bool s1 = j.dGup != nullptr, s2 = j.dGnext != nullptr;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (j.dGup) skinny_accum_kk(acc0, acc1, j.dGup, (long)arow * G, j.WxTup, wrow * G, G, wave, lane);
-    if (j.dGnext) skinny_accum_kk(acc0, acc1, j.dGnext, (long)arow * G, j.WhT, wrow * G, G, wave, lane);
-    skinny_store_partial(red, acc0, acc1, wave, lane);
+    if constexpr (CH <= 4) {  // both sources' operands fit the 128-VGPR budget of a 1024-thread block
+        SkinnyFrag<CH> f1, f2;
+        if (s1) skinny_load<CH>(f1, j.dGup, (long)arow * G, j.WxTup, wrow * G, wave, lane);
+        if (s2) skinny_load<CH>(f2, j.dGnext, (long)arow * G, j.WhT, wrow * G, wave, lane);
+        if (s1) skinny_mfma<CH>(f1, acc0, acc1);
+        if (s2) skinny_mfma<CH>(f2, acc0, acc1);
+    } else {
+        SkinnyFrag<CH> f;
+        if (s1) {
+            skinny_load<CH>(f, j.dGup, (long)arow * G, j.WxTup, wrow * G, wave, lane);
+            skinny_mfma<CH>(f, acc0, acc1);
+        }
+        if (s2) {
+            skinny_load<CH>(f, j.dGnext, (long)arow * G, j.WhT, wrow * G, wave, lane);
+            skinny_mfma<CH>(f, acc0, acc1);
+        }
+    }
+    skinny_store_partial_n(red, acc0, acc1, wave, lane);
     __syncthreads();
-    const int row = tid >> 4, col = tid & 15;
-    const int b = r0 + row;
-    if (b < B) {
-        const int unit = u0 + col;
-        const long hb = (long)b * H + unit;
-        float dh = skinny_reduced(red, row, col);
-        if (j.dhext) dh += j.dhext[(long)b * j.dhext_ld + unit];
-        const float* gp = j.gates + (long)b * G + unit;
-        const float i = gp[0], f = gp[H], g = gp[2 * H], o = gp[3 * H];
-        const float tc = tanhf(j.c[hb]);
-        const float d_o = dh * tc * o * (1.f - o);
-        float dc = dh * o * (1.f - tc * tc);
-        if (j.dcin) dc += j.dcin[hb];
-        const float d_i = dc * g * i * (1.f - i);
-        const float d_f = j.cprev ? dc * j.cprev[hb] * f * (1.f - f) : 0.f;
-        const float d_g = dc * i * (1.f - g * g);
-        j.dcout[hb] = dc * f;
-        float* dp = j.dG + (long)b * G + unit;
-        dp[0] = d_i;
-        dp[H] = d_f;
-        dp[2 * H] = d_g;
-        dp[3 * H] = d_o;
+    if (tid < 256) {
+        const int row = tid >> 4, col = tid & 15;
+        const int b = r0 + row;
+        if (b < B) {
+            const int unit = u0 + col;
+            const long hb = (long)b * H + unit;
+            float dh = skinny_reduced_n<16>(red, row, col);
+            if (j.dhext) dh += j.dhext[(long)b * j.dhext_ld + unit];
+            const float* gp = j.gates + (long)b * G + unit;
+            const float i = gp[0], f = gp[H], g = gp[2 * H], o = gp[3 * H];
+            const float tc = tanhf(j.c[hb]);
+            const float d_o = dh * tc * o * (1.f - o);
+            float dc = dh * o * (1.f - tc * tc);
+            if (j.dcin) dc += j.dcin[hb];
+            const float d_i = dc * g * i * (1.f - i);
+            const float d_f = j.cprev ? dc * j.cprev[hb] * f * (1.f - f) : 0.f;
+            const float d_g = dc * i * (1.f - g * g);
+            j.dcout[hb] = dc * f;
+            float* dp = j.dG + (long)b * G + unit;
+            dp[0] = d_i;
+            dp[H] = d_f;
+            dp[2 * H] = d_g;
+            dp[3 * H] = d_o;
+        }
     }
 }
+
+template <int CH>
+void launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_fwd_step_kernel<CH>, grid, dim3(256), 0, s, a);
+}
+template <int CH>
+void launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_bwd_step_kernel<CH>, grid, dim3(1024), 0, s, a);
+}
+
+#define DISPATCH_CH(H, FN, ...)                         \
+    switch ((H) / 64) {                                 \
+        case 1: FN<1>(__VA_ARGS__); break;              \
+        case 2: FN<2>(__VA_ARGS__); break;              \
+        case 3: FN<3>(__VA_ARGS__); break;              \
+        case 4: FN<4>(__VA_ARGS__); break;              \
+        case 5: FN<5>(__VA_ARGS__); break;              \
+        case 6: FN<6>(__VA_ARGS__); break;              \
+        case 7: FN<7>(__VA_ARGS__); break;              \
+        case 8: FN<8>(__VA_ARGS__); break;              \
+        default: return ARCVAE_ERR_ARG;                 \
+    }
+
+inline bool hidden_ok(int H) { return H > 0 && (H % 64) == 0 && H <= 512; }
 
 }  // namespace
 
@@ -148,13 +202,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(BwdArgs a) {
 //   x_tb   [T,B] tokens (time-major)          table0 [V,4H] = emb . Wx_0^T + bias_0
 //   Wx[l]  [4H,H] (l >= 1), Wh[l] [4H,H], bias[l] [4H] (l >= 1): HOST arrays of device pointers
 //   hseq/cseq [L,T,B,H], gseq [L,T,B,4H] outputs (gseq = post-activation i,f,g,o)
+//   hidden_dim: multiple of 64, <= 512.
 extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq,
                                        float* cseq, float* gseq, int B, int T, int V, int H, int L,
                                        hipStream_t stream) {
     if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq) return ARCVAE_ERR_ARG;
-    if (B <= 0 || T <= 0 || V <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || H <= 0 || (H % 64) != 0)
-        return ARCVAE_ERR_ARG;
+    if (B <= 0 || T <= 0 || V <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
@@ -177,12 +231,10 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             j.h = hseq + l * lH + t * sH;
             j.c = cseq + l * lH + t * sH;
             j.gates = gseq + l * lG + t * sG;
-            j.Kin = H;
-            j.pad = 0;
         }
         for (int k = nj; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
         dim3 grid(H / 4, ceil_div(B, 16), nj);
-        hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, stream, a);
+        DISPATCH_CH(H, launch_fwd, a, grid, stream)
     }
     return arcvae_launch_status();
 }
@@ -195,7 +247,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                         float* dcs, float* wT, int B, int T, int H, int L, hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !wT) return ARCVAE_ERR_ARG;
-    if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || H <= 0 || (H % 64) != 0 || ld_dh_top < H)
+    if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
@@ -239,7 +291,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         }
         for (int k = nj; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
         dim3 grid(H / 16, ceil_div(B, 16), nj);
-        hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, stream, a);
+        DISPATCH_CH(H, launch_bwd, a, grid, stream)
     }
     return arcvae_launch_status();
 }
@@ -276,8 +328,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     if (hipMemsetAsync(dtable_ws, 0, (size_t)V * G * sizeof(float), stream) != hipSuccess) return ARCVAE_ERR_LAUNCH;
     rc = arcvae_segsum_rows_accum(dG, x_tb, TB, V, G, dtable_ws, stream);
     if (rc) return rc;
-    rc = arcvae_gemm_f32(0, 0, V, E, G, dtable_ws, G, Wx0, E, dEmb, E, nullptr,
-                         ARCVAE_GEMM_ACCUMULATE, stream);
+    rc = arcvae_gemm_f32(0, 0, V, E, G, dtable_ws, G, Wx0, E, dEmb, E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
     if (rc) return rc;
     rc = arcvae_gemm_f32(1, 0, G, E, V, dtable_ws, G, emb, E, dWx[0], E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
     if (rc) return rc;

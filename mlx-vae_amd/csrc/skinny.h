@@ -9,80 +9,121 @@
 // MFMA 16x16x4 f32 operand maps (cdna guide section 3): lane l supplies
 // A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D: col = l&15, row = 4*(l>>4)+reg.
 // The k index inside one MFMA is only summed over, so any bijection between (step, l>>4)
-// and the wave's K-slice is valid as long as A and B use the same one.  We give each
-// 16-lane group q a CONTIGUOUS run of the slice, so a lane's A and B operands are plain
-// float4 loads.
+// and the wave's K-slice is valid as long as A and B use the same one.  We cut the slice
+// into 16-float chunks and give 16-lane group q floats [4q, 4q+4) of every chunk: a lane's A
+// and B operands are plain float4 loads AND the four q-lanes of a row read 64 contiguous
+// bytes per instruction (two chunks = one 128-B line), i.e. 16 lines per wave-instruction
+// instead of 64.  (The first version gave each q a contiguous run of the slice -- 64 distinct
+// lines per instruction, TA-bound: 7.5 us / 13.6 us per fwd / bwd step launch, profiles/r01_first.)
 #pragma once
 #include "common.h"
 
+#define SKINNY_MFMA4(a, b)                                                   \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((a).x, (b).x, acc0, 0, 0, 0); \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((a).y, (b).y, acc1, 0, 0, 0); \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((a).z, (b).z, acc0, 0, 0, 0); \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((a).w, (b).w, acc1, 0, 0, 0);
+
 // Accumulate sum_k A[arow][k] * W[wrow][k] over this wave's quarter of [0,K) into acc0/acc1.
 // A and W are K-contiguous rows (16-byte aligned, K % 64 == 0).  Lane (j = l&15, q = l>>4):
-// arow = the A row of tile row (l&15) (clamped by the caller), wrow = the W row feeding tile
-// column (l&15).
+// arow_off = element offset of the A row of tile row (l&15) (clamped by the caller),
+// wrow_off = element offset of the W row feeding tile column (l&15).
 __device__ __forceinline__ void skinny_accum_kk(f32x4& acc0, f32x4& acc1,
                                                 const float* __restrict__ A, long arow_off,
                                                 const float* __restrict__ W, long wrow_off,
                                                 int K, int wave, int lane) {
-    const int Kw = K >> 2;          // per wave
-    const int Kq = Kw >> 2;         // per 16-lane group (multiple of 4)
-    const int kbase = wave * Kw + (lane >> 4) * Kq;
-    const float4* ap = reinterpret_cast<const float4*>(A + arow_off + kbase);
+    const int Kw = K >> 2;  // per wave, a multiple of 16
+    const int kbase = wave * Kw + (lane >> 4) * 4;
+    const float4* ap = reinterpret_cast<const float4*>(A + arow_off + kbase);  // chunk c at ap[4c]
     const float4* wp = reinterpret_cast<const float4*>(W + wrow_off + kbase);
-    const int nchunk = Kq >> 2;
+    const int nchunk = Kw >> 4;
     int c = 0;
     for (; c + 4 <= nchunk; c += 4) {
-        float4 a0 = ap[c], a1 = ap[c + 1], a2 = ap[c + 2], a3 = ap[c + 3];
-        float4 b0 = wp[c], b1 = wp[c + 1], b2 = wp[c + 2], b3 = wp[c + 3];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, b2.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, b2.w, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, b3.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, b3.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, b3.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, b3.w, acc1, 0, 0, 0);
+        const float4 a0 = ap[4 * c], a1 = ap[4 * c + 4], a2 = ap[4 * c + 8], a3 = ap[4 * c + 12];
+        const float4 b0 = wp[4 * c], b1 = wp[4 * c + 4], b2 = wp[4 * c + 8], b3 = wp[4 * c + 12];
+        SKINNY_MFMA4(a0, b0)
+        SKINNY_MFMA4(a1, b1)
+        SKINNY_MFMA4(a2, b2)
+        SKINNY_MFMA4(a3, b3)
     }
     for (; c < nchunk; ++c) {
-        float4 a0 = ap[c];
-        float4 b0 = wp[c];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc1, 0, 0, 0);
+        const float4 a0 = ap[4 * c];
+        const float4 b0 = wp[4 * c];
+        SKINNY_MFMA4(a0, b0)
     }
 }
 
-// Same contraction with W stored [K][N] (N-contiguous): lane reads W[k][wcol], one dword per MFMA.
+// Same contraction with W stored [K][N] (N-contiguous): lane reads W[k][wcol], one dword per MFMA
+// (16 consecutive lanes read 64 contiguous bytes of one k-row).
 __device__ __forceinline__ void skinny_accum_kn(f32x4& acc0, f32x4& acc1,
                                                 const float* __restrict__ A, long arow_off,
                                                 const float* __restrict__ W, int ldw, int wcol,
                                                 int K, int wave, int lane) {
     const int Kw = K >> 2;
-    const int Kq = Kw >> 2;
-    const int kbase = wave * Kw + (lane >> 4) * Kq;
+    const int kbase = wave * Kw + (lane >> 4) * 4;
     const float4* ap = reinterpret_cast<const float4*>(A + arow_off + kbase);
     const float* wp = W + (long)kbase * ldw + wcol;
-    const int nchunk = Kq >> 2;
-#pragma unroll 2
+    const int nchunk = Kw >> 4;
+#pragma unroll 4
     for (int c = 0; c < nchunk; ++c) {
-        float4 a0 = ap[c];
-        float b0 = wp[(long)(4 * c + 0) * ldw];
-        float b1 = wp[(long)(4 * c + 1) * ldw];
-        float b2 = wp[(long)(4 * c + 2) * ldw];
-        float b3 = wp[(long)(4 * c + 3) * ldw];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b2, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b3, acc1, 0, 0, 0);
+        const float4 a0 = ap[4 * c];
+        float4 b0;
+        b0.x = wp[(long)(16 * c + 0) * ldw];
+        b0.y = wp[(long)(16 * c + 1) * ldw];
+        b0.z = wp[(long)(16 * c + 2) * ldw];
+        b0.w = wp[(long)(16 * c + 3) * ldw];
+        SKINNY_MFMA4(a0, b0)
     }
+}
+
+// ---- static (all loads first) form ---------------------------------------------------------
+// The step kernels run one block per CU-ish with nothing else to hide memory latency behind, so a
+// loop of {8 loads -> wait -> 16 MFMA} exposes one full L2/Infinity-Cache round trip per
+// iteration (8 of them in the first BPTT step kernel: 10 us per launch).  SkinnyFrag holds a wave's
+// whole K-slice of both operands in registers: every load of every source is issued before the
+// first MFMA, so the round trip is paid once.  CH = 16-float chunks per wave and source.
+template <int CH>
+struct SkinnyFrag {
+    float4 a[CH];
+    float4 w[CH];
+};
+
+// Kw = K-slice per wave = 16*CH floats; wave w of NW covers [w*Kw, (w+1)*Kw).
+template <int CH>
+__device__ __forceinline__ void skinny_load(SkinnyFrag<CH>& f, const float* __restrict__ A, long arow_off,
+                                            const float* __restrict__ W, long wrow_off, int wave, int lane) {
+    const int kbase = wave * (16 * CH) + (lane >> 4) * 4;
+    const float4* ap = reinterpret_cast<const float4*>(A + arow_off + kbase);
+    const float4* wp = reinterpret_cast<const float4*>(W + wrow_off + kbase);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        f.a[c] = ap[4 * c];
+        f.w[c] = wp[4 * c];
+    }
+}
+
+template <int CH>
+__device__ __forceinline__ void skinny_mfma(const SkinnyFrag<CH>& f, f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { SKINNY_MFMA4(f.a[c], f.w[c]) }
+}
+
+// NW-wave variants of the partial-tile exchange: red[NW][16][16].
+__device__ __forceinline__ void skinny_store_partial_n(float* red, const f32x4& acc0, const f32x4& acc1,
+                                                       int wave, int lane) {
+    float* p = red + wave * 256 + ((lane >> 4) * 4) * 16 + (lane & 15);
+    p[0] = acc0[0] + acc1[0];
+    p[16] = acc0[1] + acc1[1];
+    p[32] = acc0[2] + acc1[2];
+    p[48] = acc0[3] + acc1[3];
+}
+template <int NW>
+__device__ __forceinline__ float skinny_reduced_n(const float* red, int row, int col) {
+    const int o = row * 16 + col;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * 256 + o];
+    return s;
 }
 
 // Write this wave's 16x16 partial tile to LDS as red[wave][row][col] (row-major, 16 cols).
