@@ -96,6 +96,16 @@ int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* 
                               float* dWlh, float* dblh, float* dWlv, float* dblv, int B, int H, int Z, int C,
                               arcvae_stream_t stream);
 
+/* ---- stand-alone loss pieces (the reference's `losses` module called on arbitrary tensors) ----------
+ * models/encoder.py:147-153; losses/kl.py:39-58 + losses/info.py:27-35 partial sums (krow [B] may
+ * be NULL: per-sample free-bits KL); losses/recon.py:29-57 per-position CE; out[0] = scale*sum(x). */
+int arcvae_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, long n,
+                          arcvae_stream_t stream);
+int arcvae_latent_stats(const float* mu, const float* logvar, float* stats, float* krow, int B, int Z,
+                        float free_bits, arcvae_stream_t stream);
+int arcvae_ce_rows(const float* logits, const int32_t* targets, float* ce, long R, int V, arcvae_stream_t stream);
+int arcvae_sum(const float* x, long n, float* out, float scale, arcvae_stream_t stream);
+
 /* ---- decoder, vocabulary-dense ------------------------------------------------------------------
  * models/decoder.py:152-175: per step embed(token) ++ conditions -> L zero-state LSTM cells
  * (hidden=None, cell=None every call, Q1) -> fc_out.  logits_t depends only on (token_t, cond_b),

@@ -47,6 +47,10 @@ SIGNATURES = {
     "arcvae_dec_sample_chain": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "arcvae_dec_backward_dense": [_vp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _pp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "arcvae_reparameterize": [_vp, _vp, _vp, _vp, _l, _vp],
+    "arcvae_latent_stats": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "arcvae_ce_rows": [_vp, _vp, _vp, _l, _i, _vp],
+    "arcvae_sum": [_vp, _l, _vp, _f, _vp],
     "arcvae_adam_update": [_vp, _vp, _vp, _vp, _l, _d, _d, _d, _d, _vp],
     "arcvae_colsum_accum": [_vp, _i, _i, _i, _vp, _f, _vp],
     "arcvae_segsum_rows_accum": [_vp, _vp, _i, _i, _i, _vp, _vp],

@@ -1,0 +1,71 @@
+"""Glue between the reference-named modules and the step engine: engine cache, loss forward,
+value_and_grad (the mx.value_and_grad of trainer.py:292) and RNG conventions (Q5/Q18)."""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .engine import SCALAR_KEYS, StepEngine
+
+_ENGINES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def engine_for(encoder, decoder) -> StepEngine:
+    """One StepEngine (workspaces, side stream, captured graphs) per (encoder, decoder) pair."""
+    per_enc = _ENGINES.setdefault(encoder, {})
+    key = id(decoder)
+    if key not in per_enc:
+        if encoder.dims != decoder.dims:
+            raise ValueError("encoder and decoder were built with different dimensions")
+        per_enc[key] = StepEngine(encoder.store, decoder.store, encoder.dims)
+    return per_enc[key]
+
+
+def draw_coins(T: int, ratio: float) -> np.ndarray:
+    """models/decoder.py:180: one np.random.rand() per timestep from the GLOBAL legacy stream, drawn even
+    when ratio == 0.0 (validation)."""
+    return np.array([np.random.rand() < ratio for _ in range(T)], dtype=np.uint8)
+
+
+def draw_eps(B: int, Z: int, device, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """The reference draws eps from MLX's unseeded global RNG (Q18): any N(0,1) draw is 'the same'."""
+    return torch.randn(B, Z, device=device, dtype=torch.float32, generator=generator)
+
+
+def _as_dict(eng: StepEngine, ws, clone: bool) -> Dict[str, torch.Tensor]:
+    sc = ws.scalars.clone()  # 16 floats: always detach from the static buffer the next call overwrites
+    out = {k: sc[i] for i, k in enumerate(SCALAR_KEYS)}
+    for k in ("mu", "logvar", "z"):
+        t = getattr(ws, k)
+        out[k] = t.clone() if clone else t
+    return out
+
+
+def loss_forward(encoder, decoder, x, conditions, eps=None, coins=None, teacher_forcing_ratio: float = 0.9,
+                 **hyper) -> Dict[str, torch.Tensor]:
+    eng = engine_for(encoder, decoder)
+    B, T = int(x.shape[0]), int(x.shape[1])
+    if coins is None:
+        coins = draw_coins(T, teacher_forcing_ratio)
+    if eps is None:
+        eps = draw_eps(B, encoder.latent_dim, encoder.store.device)
+    eng.forward_loss(x, conditions, eps, coins, **hyper)
+    return _as_dict(eng, eng.workspace(B, T, train=False), clone=True)
+
+
+def value_and_grad(encoder, decoder, x, conditions, eps=None, coins=None, teacher_forcing_ratio: float = 0.9,
+                   lr: Optional[float] = None, **hyper):
+    """(loss dict, (encoder grad tree, decoder grad tree)); with `lr` given the two Adam updates are applied
+    in the same captured step (trainer.py:305-333)."""
+    eng = engine_for(encoder, decoder)
+    B, T = int(x.shape[0]), int(x.shape[1])
+    if coins is None:
+        coins = draw_coins(T, teacher_forcing_ratio)
+    if eps is None:
+        eps = draw_eps(B, encoder.latent_dim, encoder.store.device)
+    eng.train_step(x, conditions, eps, coins, lr=lr if lr is not None else 0.0, update=lr is not None, **hyper)
+    ws = eng.workspace(B, T, train=True)
+    return _as_dict(eng, ws, clone=False), (encoder.gradients(), decoder.gradients())

@@ -262,3 +262,111 @@ extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, co
     if ((rc = arcvae_colsum_accum(dcomb + H, B, H, H2, dbc, 1.0f, stream))) return rc;
     return arcvae_launch_status();
 }
+
+// =============================================================================================
+// Stand-alone forms of the loss pieces, for the reference's `losses` module API
+// (losses/recon.py, losses/kl.py, losses/info.py called on arbitrary tensors).  The training step
+// does not use these: it runs the fused kernels above.
+// =============================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                      const float* __restrict__ eps, float* z, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = mu[i] + eps[i] * expf(0.5f * logvar[i]);
+}
+
+// stats (layout at the top of this file) from given mu/logvar; krow[b] (optional) = per-sample free-bits KL
+__global__ __launch_bounds__(256) void latent_stats_kernel(const float* __restrict__ mu,
+                                                           const float* __restrict__ logvar, float* stats,
+                                                           float* krow, int B, int Z, float fb_min) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    float klmi = 0.f, klfb = 0.f;
+    for (int j = lane; j < Z; j += 64) {
+        const long i = (long)b * Z + j;
+        const float mc = clipf(mu[i], -3.0f, 3.0f), lc = clipf(logvar[i], -6.0f, 3.0f);
+        const float var = expf(lc);
+        const float k = -0.5f * (1.0f + lc - mc * mc - var);
+        atomicAdd(stats + j, mc);
+        atomicAdd(stats + Z + j, var);
+        klmi += k;
+        float kf = fmaxf(k, 0.0f);
+        if (fb_min > 0.0f) kf = fmaxf(kf, fb_min);
+        klfb += kf;
+    }
+    klmi = wave_sum(klmi);
+    klfb = wave_sum(klfb);
+    if (lane == 0) {
+        atomicAdd(stats + 2 * Z, klmi);
+        atomicAdd(stats + 2 * Z + 1, klfb);
+        atomicAdd(stats + 2 * Z + 2, 1.0f);
+        if (krow) krow[b] = klfb;
+    }
+}
+
+// ce[r] = logsumexp(logits[r]) - logits[r, target[r]]   (one wave per row)
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits,
+                                                      const int32_t* __restrict__ targets, float* ce, long R, int V) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* x = logits + r * V;
+    float m = -INFINITY;
+    for (int w = lane; w < V; w += 64) m = fmaxf(m, x[w]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int w = lane; w < V; w += 64) s += expf(x[w] - m);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int t = min(max(targets[r], 0), V - 1);
+        ce[r] = -((x[t] - m) - logf(s));
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_scaled_kernel(const float* __restrict__ x, long n, float* out, float scale) {
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
+}  // namespace
+
+// models/encoder.py:147-153 with eps supplied by the caller.
+extern "C" int arcvae_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, long n,
+                                     hipStream_t stream) {
+    if (!mu || !logvar || !eps || !z || n <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mu, logvar, eps, z, n);
+    return arcvae_launch_status();
+}
+
+// losses/kl.py:39-58 + losses/info.py:27-35 partial sums for given mu/logvar (stats zeroed here).
+extern "C" int arcvae_latent_stats(const float* mu, const float* logvar, float* stats, float* krow, int B, int Z,
+                                   float free_bits, hipStream_t stream) {
+    if (!mu || !logvar || !stats || B <= 0 || Z <= 0) return ARCVAE_ERR_ARG;
+    if (hipMemsetAsync(stats, 0, (size_t)(2 * Z + 4) * sizeof(float), stream) != hipSuccess) return ARCVAE_ERR_LAUNCH;
+    const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
+    hipLaunchKernelGGL(latent_stats_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, mu, logvar, stats, krow, B, Z,
+                       fb_min);
+    return arcvae_launch_status();
+}
+
+// losses/recon.py:29-57 per-position cross entropy.
+extern "C" int arcvae_ce_rows(const float* logits, const int32_t* targets, float* ce, long R, int V,
+                              hipStream_t stream) {
+    if (!logits || !targets || !ce || R <= 0 || V <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, logits, targets, ce, R, V);
+    return arcvae_launch_status();
+}
+
+// out[0] = scale * sum(x)
+extern "C" int arcvae_sum(const float* x, long n, float* out, float scale, hipStream_t stream) {
+    if (!x || !out || n <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(sum_scaled_kernel, dim3(1), dim3(256), 0, stream, x, n, out, scale);
+    return arcvae_launch_status();
+}

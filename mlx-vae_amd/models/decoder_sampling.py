@@ -1,0 +1,74 @@
+"""MLXAutoregressiveDecoderSampling on MI355X (reference models/decoder_sampling.py:6-129).
+
+Owns its OWN, never-trained decoder (Q9: not weight-shared with ARCVAE.decoder); "temperature
+sampling" is argmax(softmax(logits / T)) = greedy; tokens after EOS are still generated; with
+early stopping the output is cut where every row has emitted EOS.  One dense decoder pass
+(B*V rows) + one table walk replaces the reference's max_length dependent steps and its per-step
+host sync; `load_from_decoder` is an explicit extension to sample from trained weights."""
+from __future__ import annotations
+
+import torch
+
+from arcvae_hip import engine as E
+from arcvae_hip._lib import call, ptr, stream_ptr
+from arcvae_hip.module import as_f32
+
+from .decoder import MLXAutoregressiveDecoder
+
+
+class MLXAutoregressiveDecoderSampling:
+    def __init__(self, vocab_size: int, embedding_dim: int = 256, hidden_dim: int = 512, latent_dim: int = 200,
+                 num_conditions: int = 6, num_layers: int = 3, pad_token: int = 0, end_token: int = 2, device=None,
+                 generator=None):
+        self.decoder = MLXAutoregressiveDecoder(vocab_size, embedding_dim, hidden_dim, latent_dim, num_conditions,
+                                                num_layers, pad_token, end_token, device=device, generator=generator)
+        self.vocab_size, self.embedding_dim, self.hidden_dim = vocab_size, embedding_dim, hidden_dim
+        self.latent_dim, self.num_conditions = latent_dim, num_conditions
+        self.pad_token, self.end_token = pad_token, end_token
+        self._graphs = {}
+
+    def load_from_decoder(self, other: MLXAutoregressiveDecoder) -> None:
+        """Extension (absent in the reference): copy trained decoder weights into the sampler."""
+        self.decoder.store.flat.copy_(other.store.flat)
+
+    def parameters(self):
+        return {"decoder": self.decoder.parameters()}
+
+    def generate_with_temperature(self, z, conditions, max_length: int = 80, temperature: float = 1.0,
+                                  early_stopping: bool = True, use_graph: bool = True) -> torch.Tensor:
+        """[B, t_stop] int32 tokens (models/decoder_sampling.py:48-128).  z is accepted and unused (Q2)."""
+        dec = self.decoder
+        dev = dec.store.device
+        cond = as_f32(conditions, dev)
+        B = cond.shape[0]
+        ws = dec.workspace(B, max_length)
+        ws.cond.copy_(cond.reshape(B, dec.num_conditions))
+        key = (B, max_length, float(temperature))
+        if key not in self._graphs:
+            self._graphs[key] = dict(tokens=torch.zeros(B, max_length, dtype=torch.int32, device=dev),
+                                     first_end=torch.zeros(B, dtype=torch.int32, device=dev), graph=None)
+        st = self._graphs[key]
+
+        def enqueue():
+            E.decoder_forward_dense(dec.store, ws, dec.dims, mode=1, temperature=temperature)
+            call("arcvae_dec_sample_chain", ptr(ws.nxt), ptr(st["tokens"]), ptr(st["first_end"]), B, dec.vocab_size,
+                 max_length, dec.end_token, stream_ptr())
+
+        if not use_graph:
+            enqueue()
+        elif st["graph"] is None:
+            enqueue()  # first call runs eagerly, then the decode pass is captured for replay
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enqueue()
+            st["graph"] = g
+        else:
+            st["graph"].replay()
+        tokens = st["tokens"]
+        if early_stopping:
+            # reference: the loop breaks at the first step t where every row has already ended, i.e. after
+            # max_b(first EOS index) + 1 tokens; one host read replaces its per-step mx.all() sync
+            t_stop = int(st["first_end"].max().item()) + 1
+            tokens = tokens[:, :min(t_stop, max_length)]
+        return tokens.clone()

@@ -1,0 +1,262 @@
+"""GPU tests of the reference-named Python surface (models/, losses/, complete_vae_loss, mlx_data,
+trainer, train.py) against the oracle: these read like the reference's own call sites."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import arcvae_oracle as O
+from helpers import HYPER, SMALL, TINY, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _vae(cfg, params):
+    from models.vae import ARCVAE
+    vae = ARCVAE(vocab_size=cfg.V, embedding_dim=cfg.E, hidden_dim=cfg.H, latent_dim=cfg.Z,
+                 num_conditions=cfg.C, num_layers=cfg.L, dropout=0.2)
+    vae.encoder.load_state_dict(params, prefix="encoder.")
+    vae.decoder.load_state_dict(params, prefix="decoder.")
+    return vae
+
+
+def _oracle_forward(cfg, params, x, cond, eps, coins, dtype=torch.float64):
+    p = O.to_torch(params, dtype)
+    return O.complete_vae_loss(p, cfg, torch.tensor(x), torch.tensor(cond, dtype=dtype),
+                               torch.tensor(eps, dtype=dtype), coins, **HYPER)
+
+
+def test_arcvae_call_matches_reference_forward():
+    cfg, B, T = TINY, 5, 14
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    ref = _oracle_forward(cfg, params, x, cond, eps, coins)
+    vae = _vae(cfg, params)
+    logits, mu, logvar, z = vae(x, cond, target_seq=x, teacher_forcing_ratio=0.6, eps=torch.tensor(eps), coins=coins)
+    assert tuple(logits.shape) == (B, T, cfg.V) and tuple(z.shape) == (B, cfg.Z)
+    assert rel_err(logits.cpu().numpy(), ref["logits"].numpy()) < TOL
+    assert rel_err(mu.cpu().numpy(), ref["mu"].numpy()) < TOL
+    assert rel_err(logvar.cpu().numpy(), ref["logvar"].numpy()) < TOL
+    assert rel_err(z.cpu().numpy(), ref["z"].numpy()) < TOL
+
+
+def test_decoder_draws_coins_from_the_global_numpy_stream():
+    cfg, B, T = TINY, 4, 12
+    params, x, cond, eps, _ = make_case(cfg, B, T, 0.5)
+    vae = _vae(cfg, params)
+    np.random.seed(123)
+    got = vae.decoder(torch.zeros(B, cfg.Z), cond, target_seq=x, teacher_forcing_ratio=0.5).cpu().numpy()
+    after = np.random.rand()
+    coins = O.draw_coins(np.random.RandomState(123), T, 0.5)
+    pd = {k[len("decoder."):]: torch.tensor(v, dtype=torch.float64) for k, v in params.items() if k.startswith("decoder.")}
+    ref, _ = O.decoder_forward(pd, torch.zeros(B, cfg.Z, dtype=torch.float64), torch.tensor(cond, dtype=torch.float64),
+                               cfg.L, torch.tensor(x), coins)
+    assert rel_err(got, ref.numpy()) < TOL
+    assert after == np.random.RandomState(123).rand(T + 1)[-1]  # exactly T draws were consumed
+
+
+def test_decoder_without_target_free_runs_max_length():
+    cfg, B = TINY, 3
+    params, x, cond, eps, _ = make_case(cfg, B, 12, 0.5)
+    vae = _vae(cfg, params)
+    np.random.seed(5)
+    out = vae.decoder(torch.zeros(B, cfg.Z), cond)  # target_seq=None -> max_length=80 argmax steps, no coins
+    assert np.random.rand() == np.random.RandomState(5).rand()  # stream untouched (decoder.py:180 short-circuit)
+    pd = {k[len("decoder."):]: torch.tensor(v, dtype=torch.float64) for k, v in params.items() if k.startswith("decoder.")}
+    ref, _ = O.decoder_forward(pd, None if False else torch.zeros(B, cfg.Z, dtype=torch.float64),
+                               torch.tensor(cond, dtype=torch.float64), cfg.L, None, None, max_length=80)
+    assert tuple(out.shape) == (B, 80, cfg.V)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_complete_vae_loss_dict():
+    from complete_vae_loss import complete_vae_loss
+    cfg, B, T = SMALL, 9, 11
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.5)
+    ref = _oracle_forward(cfg, params, x, cond, eps, coins)
+    vae = _vae(cfg, params)
+    out = complete_vae_loss(vae.encoder, vae.decoder, None, x, cond, beta=HYPER["beta"], lambda_prop=0.1,
+                            lambda_collapse=HYPER["lambda_collapse"], teacher_forcing_ratio=0.5,
+                            free_bits=HYPER["free_bits"], lambda_mi=HYPER["lambda_mi"], target_mi=4.85,
+                            eps=torch.tensor(eps), coins=coins)
+    assert set(out) == {"total_loss", "recon_loss", "kl_loss", "weighted_kl", "collapse_penalty", "prop_loss",
+                        "weighted_prop_loss", "mutual_info", "mi_penalty", "mu", "logvar", "z"}
+    for k in ("total_loss", "recon_loss", "kl_loss", "weighted_kl", "collapse_penalty", "mutual_info", "mi_penalty"):
+        assert abs(float(out[k]) - float(ref[k])) <= TOL * max(1.0, abs(float(ref[k]))), k
+    assert float(out["prop_loss"]) == 0.0 and float(out["weighted_prop_loss"]) == 0.0
+
+
+def test_standalone_losses_on_reference_test_shapes():
+    """Shapes and input distributions of the reference's test_loss_signs.py:19-53."""
+    from losses import kl_divergence, mutual_information, posterior_collapse, reconstruction_loss
+    rs = np.random.RandomState(0)
+    B, T, V, Z = 32, 120, 95, 128
+    logits = rs.standard_normal((B, T, V)).astype(np.float32)
+    targets = rs.randint(0, V, (B, T))
+    mu = (rs.standard_normal((B, Z)) * 0.1).astype(np.float32)
+    logvar = (rs.standard_normal((B, Z)) * 0.1 - 1.0).astype(np.float32)
+    tl, tt = torch.tensor(logits, dtype=torch.float64), torch.tensor(targets)
+    tm, tv = torch.tensor(mu, dtype=torch.float64), torch.tensor(logvar, dtype=torch.float64)
+    dl, dm, dv = torch.tensor(logits).cuda(), torch.tensor(mu).cuda(), torch.tensor(logvar).cuda()
+    for red in ("mean", "sum", "none"):
+        a = reconstruction_loss(dl, targets, reduction=red).cpu().numpy()
+        assert rel_err(a, O.reconstruction_loss(tl, tt, red).numpy()) < TOL
+        for fb in (0.0, 1.0):
+            a = kl_divergence(dm, dv, reduction=red, free_bits=fb).cpu().numpy()
+            assert rel_err(a, O.kl_divergence(tm, tv, red, fb).numpy()) < TOL
+    assert float(reconstruction_loss(dl, targets)) >= 0 and float(kl_divergence(dm, dv)) >= 0
+    assert abs(float(mutual_information(dm, dv)) - float(O.mutual_information(tm, tv))) < 1e-4
+    assert abs(float(posterior_collapse(dm, dv, 4.85, 0.1)) - float(O.posterior_collapse(tm, tv, 4.85, 0.1))) < 1e-4
+    assert float(posterior_collapse(dm, dv, 4.85, 0.1)) >= 0
+
+
+@pytest.mark.parametrize("early", [True, False])
+def test_generate_matches_reference_sampler(early):
+    cfg, B = TINY, 37
+    params = O.init_params(cfg, 1234)
+    vae = _vae(cfg, params)
+    vae.decoder_sampling.load_from_decoder(vae.decoder)
+    cond = np.random.RandomState(9).standard_normal((B, cfg.C)).astype(np.float32)
+    pd = {k[len("decoder."):]: torch.tensor(v) for k, v in params.items() if k.startswith("decoder.")}
+    for temp in (1.0, 0.7):
+        ref = O.generate_with_temperature(pd, torch.tensor(cond), cfg.L, max_length=30, temperature=temp,
+                                          early_stopping=early).numpy()
+        for _ in range(2):  # second call replays the captured hipGraph
+            got = vae.decoder_sampling.generate_with_temperature(torch.zeros(B, cfg.Z), cond, max_length=30,
+                                                                 temperature=temp, early_stopping=early)
+            assert got.dtype == torch.int32 and tuple(got.shape) == ref.shape
+            assert np.array_equal(got.cpu().numpy(), ref)
+    out = vae.generate(B, cond, max_length=16)
+    assert out.shape[0] == B and out.shape[1] <= 16
+
+
+def test_early_stopping_cuts_where_every_row_has_ended():
+    """Force EOS: a decoder whose fc_out bias makes token 2 the argmax everywhere stops after 1 token."""
+    cfg, B = TINY, 6
+    params = O.init_params(cfg, 1234)
+    params["decoder.fc_out.bias"][2] = 50.0
+    vae = _vae(cfg, params)
+    vae.decoder_sampling.load_from_decoder(vae.decoder)
+    cond = np.zeros((B, cfg.C), np.float32)
+    got = vae.decoder_sampling.generate_with_temperature(torch.zeros(B, cfg.Z), cond, max_length=20)
+    assert tuple(got.shape) == (B, 1) and int(got.min()) == 2
+    full = vae.decoder_sampling.generate_with_temperature(torch.zeros(B, cfg.Z), cond, max_length=20, early_stopping=False)
+    assert tuple(full.shape) == (B, 20)  # tokens after EOS are still generated (Q9)
+
+
+def test_dataset_batches_ragged_tail_and_shuffle_order():
+    from mlx_data.dataloader import MoleculeDataset
+    rs = np.random.RandomState(1)
+    mols = [list(rs.randint(3, 80, size=rs.randint(2, 30))) for _ in range(23)]
+    props = rs.standard_normal((23, 1)).astype(np.float32) * 30 + 70
+    ds = MoleculeDataset(mols, props, max_length=16, pad_token=0)
+    assert len(ds) == 23
+    assert np.allclose(ds.properties_normalized.mean(0), 0, atol=1e-5) and np.allclose(ds.properties_normalized.std(0), 1, atol=1e-5)
+    np.random.seed(42)
+    batches = list(ds.to_batches(8, shuffle=True))
+    assert [b[0].shape[0] for b in batches] == [8, 8, 7]  # final partial batch is yielded (Q14)
+    order = np.arange(23)
+    np.random.RandomState(42).shuffle(order)
+    got = torch.cat([b[0] for b in batches]).cpu().numpy()
+    for row, i in zip(got, order):
+        exp = (mols[i] + [0] * 16)[:16]
+        assert list(row) == exp  # pad / truncate to max_length (dataloader.py:76-79)
+    val = MoleculeDataset(mols[:5], props[:5], max_length=16, properties_mean=ds.properties_mean, properties_std=ds.properties_std)
+    assert np.allclose(val.properties_normalized, (props[:5] - ds.properties_mean) / ds.properties_std)
+
+
+def _reference_epoch(cfg, params, train, val, bs, T, lr, epoch, total_epochs, hp):
+    """The reference's epoch control flow (trainer.py:177-241) driven by the oracle, same RNG order."""
+    p = {k: v.copy() for k, v in params.items()}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(vv) for k, vv in p.items()}
+    beta = O.compute_beta(epoch, hp["beta_start"], hp["beta_end"], hp["warmup"])
+    tf = O.compute_teacher_forcing_ratio(epoch, total_epochs)
+    hy = dict(beta=beta, lambda_collapse=hp["lambda_collapse"], free_bits=hp["free_bits"], lambda_mi=hp["lambda_mi"])
+    eps0 = lambda n: np.zeros((n, cfg.Z), np.float32)  # loss values do not depend on eps (Q2)
+
+    def fwd(xb, cb, ratio):
+        coins = O.draw_coins(np.random, T, ratio)
+        return O.complete_vae_loss(O.to_torch(p), cfg, torch.tensor(xb), torch.tensor(cb), torch.tensor(eps0(len(xb))), coins, **hy)
+
+    idx = np.arange(len(train[0]))
+    np.random.shuffle(idx)
+    for bi, i in enumerate(range(0, len(idx), bs)):
+        sel = idx[i:i + bs]
+        coins = O.draw_coins(np.random, T, tf)
+        O.train_step(p, m, v, cfg, train[0][sel], train[1][sel], eps0(len(sel)), coins, lr, **hy)
+        if bi == 0 or bi % 25 == 0:
+            fwd(train[0][sel], train[1][sel], tf)
+
+    def evaluate(data, limit):
+        tot, n = np.zeros(3), 0
+        for bi, i in enumerate(range(0, len(data[0]), bs)):
+            if limit is not None and bi >= limit:
+                break
+            d = fwd(data[0][i:i + bs], data[1][i:i + bs], 0.0)
+            tot += [float(d["total_loss"]), float(d["recon_loss"]), float(d["kl_loss"])]
+            n += 1
+        return tot / n
+
+    tr = evaluate(train, 20)
+    va = evaluate(val, None)
+    return p, dict(train_loss=tr[0], train_recon=tr[1], train_kl=tr[2], val_loss=va[0], val_recon=va[1], val_kl=va[2],
+                   beta=beta, teacher_forcing=tf)
+
+
+def test_trainer_epoch_matches_reference_control_flow(tmp_path):
+    """ELBO components after one epoch (and the epoch after, beta > 0) follow the reference's flow to 1e-3."""
+    from mlx_data.dataloader import MoleculeDataset
+    from trainer import ARCVAETrainerWithLoss
+    cfg, T, bs = TINY, 12, 8
+    rs = np.random.RandomState(3)
+    mols = [list(rs.randint(3, cfg.V, size=rs.randint(4, T - 1))) + [2] for _ in range(44)]
+    props = (rs.standard_normal((44, 1)) * 20 + 60).astype(np.float32)
+    tr_ds = MoleculeDataset(mols[:36], props[:36], max_length=T)
+    va_ds = MoleculeDataset(mols[36:], props[36:], max_length=T, properties_mean=tr_ds.properties_mean,
+                            properties_std=tr_ds.properties_std)
+    params = O.init_params(cfg, 1234)
+    vae = _vae(cfg, params)
+    hp = dict(beta_start=0.0, beta_end=0.05, warmup=2, lambda_collapse=0.001, free_bits=1.0, lambda_mi=0.01)
+    trainer = ARCVAETrainerWithLoss(vae.encoder, vae.decoder, None, tr_ds, learning_rate=2e-4, batch_size=bs,
+                                    beta_start=0.0, beta_end=0.05, beta_warmup_epochs=2, lambda_collapse=0.001,
+                                    free_bits=1.0, lambda_mi=0.01, checkpoint_dir=str(tmp_path / "ck"), progress=False)
+    tr_np = (tr_ds._tokens.cpu().numpy().astype(np.int64), tr_ds._props.cpu().numpy())
+    va_np = (va_ds._tokens.cpu().numpy().astype(np.int64), va_ds._props.cpu().numpy())
+    p = params
+    for epoch in range(2):
+        np.random.seed(100 + epoch)
+        got = trainer.train_epoch(epoch, 3, va_ds)
+        np.random.seed(100 + epoch)
+        # the oracle epoch restarts Adam state each call, so feed it the trainer's trajectory one epoch at a time
+        if epoch == 0:
+            p, ref = _reference_epoch(cfg, p, tr_np, va_np, bs, T, 2e-4, epoch, 3, hp)
+            for k, r in ref.items():
+                assert abs(got[k] - r) <= 1e-3 * max(1.0, abs(r)), (epoch, k, got[k], r)
+            for name, r in p.items():
+                mod, pn = name.split(".", 1)
+                g = (vae.encoder if mod == "encoder" else vae.decoder).store.p(pn).cpu().numpy()
+                assert rel_err(g, r) < 1e-3, name
+    assert got["beta"] == pytest.approx(0.025) and got["mutual_info"] >= 0.0
+    # checkpoint round trip (file names of trainer.py:577-597, non-pickle contents)
+    trainer.history["epoch"].append(0)
+    trainer.save_checkpoint(0, is_best=True)
+    assert (tmp_path / "ck" / "checkpoint_best.npz").exists() and (tmp_path / "ck" / "checkpoint_epoch_000.npz").exists()
+    before = vae.encoder.store.flat.clone()
+    vae.encoder.store.flat.zero_()
+    assert trainer.load_checkpoint(str(tmp_path / "ck" / "checkpoint_best.npz")) == 0
+    assert torch.equal(vae.encoder.store.flat, before)
+    trainer.save_history(str(tmp_path / "ck"))
+    assert json.load(open(tmp_path / "ck" / "training_history.json"))["epoch"] == [0]
+
+
+def test_train_cli_smoke(tmp_path):
+    import train
+    train.main(["--synthetic", "48", "--epochs", "1", "--batch_size", "16", "--hidden_dim", "64", "--embedding_dim", "16",
+                "--latent_dim", "8", "--checkpoint_dir", str(tmp_path / "ck"), "--no_progress", "--verbose"])
+    assert (tmp_path / "ck" / "checkpoint_best.npz").exists()
+    assert (tmp_path / "ck" / "training_history.json").exists()
+    with pytest.raises(FileNotFoundError):
+        train.main(["--synthetic", "48", "--resume", "--checkpoint_dir", str(tmp_path / "none"), "--no_progress"])

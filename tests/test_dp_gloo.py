@@ -1,0 +1,158 @@
+"""world_size-2 (gloo, CPU) test of the data-parallel step driver arcvae_hip.dp.DataParallelStep.
+
+The driver's control flow (stats all-reduce seam, early/late gradient buckets, update) is the
+product code; the per-rank math behind the `ops` protocol is supplied here by the test oracle,
+split exactly the way the HIP kernels split it (per-rank partial `stats` -> global sums ->
+gradients of the GLOBAL loss w.r.t. LOCAL rows).  N ranks x shard must equal 1 process x global
+batch: loss scalars, summed gradients and post-Adam parameters.
+"""
+import contextlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import arcvae_oracle as O
+from helpers import HYPER, TINY, make_case
+
+DT = torch.float64
+
+
+class OracleOps:
+    """StepOps backed by the oracle (CPU).  stats layout = csrc/latent.hip."""
+
+    def __init__(self, cfg, params, x, cond, eps, coins, T, lr):
+        self.cfg, self.T, self.lr, self.coins = cfg, T, lr, coins
+        self.p = {k: torch.tensor(v, dtype=DT, requires_grad=True) for k, v in params.items()}
+        self.x = torch.as_tensor(x, dtype=torch.int64)
+        self.cond = torch.as_tensor(cond, dtype=DT)
+        self.eps = torch.as_tensor(eps, dtype=DT)
+        Z = cfg.Z
+        self.stats = torch.zeros(2 * Z + 4, dtype=DT)
+        self.scalars = {}
+        self.enc_names = [k for k in params if k.startswith("encoder.")]
+        self.dec_names = [k for k in params if k.startswith("decoder.")]
+        self.enc_grad = None
+        self.dec_grad = None
+        self.m = {k: np.zeros_like(v, dtype=np.float64) for k, v in params.items()}
+        self.v = {k: np.zeros_like(v, dtype=np.float64) for k, v in params.items()}
+
+    def _local_stats(self):
+        cfg = self.cfg
+        pe = {k[len("encoder."):]: v for k, v in self.p.items() if k.startswith("encoder.")}
+        pd = {k[len("decoder."):]: v for k, v in self.p.items() if k.startswith("decoder.")}
+        mu, logvar = O.encoder_forward(pe, self.x, self.cond, cfg.L)
+        z = O.reparameterize(mu, logvar, self.eps)
+        logits, _ = O.decoder_forward(pd, z, self.cond, cfg.L, self.x, self.coins)
+        ce = O.reconstruction_loss(logits, self.x, reduction="sum")
+        mc, lc = O.mlx_clip(mu, -3.0, 3.0), O.mlx_clip(logvar, -6.0, 3.0)
+        var = torch.exp(lc)
+        k = -0.5 * (1.0 + lc - mc * mc - var)
+        kf = O.mlx_maximum(O.mlx_maximum(k, 0.0), HYPER["free_bits"] / cfg.Z)
+        rows = torch.tensor([float(mu.shape[0])], dtype=DT)
+        return torch.cat([mc.sum(0), var.sum(0), k.sum().reshape(1), kf.sum().reshape(1), rows, ce.reshape(1)])
+
+    def forward_local(self):
+        self._attached = self._local_stats()
+        self.stats.copy_(self._attached.detach())
+        self._local_detached = self.stats.clone()
+
+    def backward_local(self):
+        Z, T = self.cfg.Z, self.T
+        st = self.stats.detach() - self._local_detached + self._attached   # global sums, local part differentiable
+        Bg = st[2 * Z + 2]
+        mm, mv = st[:Z] / Bg, st[Z:2 * Z] / Bg
+        agg = -0.5 * (1.0 + torch.log(mv) - mm * mm - mv).sum()
+        mi = O.mlx_maximum(st[2 * Z] / Bg - agg, 0.0)
+        d = HYPER["target_mi"] - mi
+        dpos = torch.where(torch.zeros_like(d) > d, torch.zeros_like(d), d)
+        recon = st[2 * Z + 3] / (Bg * T)
+        kl = st[2 * Z + 1] / Bg
+        total = recon + HYPER["beta"] * kl + HYPER["lambda_collapse"] * dpos + HYPER["lambda_mi"] * dpos
+        self.scalars = dict(total=float(total), recon=float(recon), kl=float(kl), mi=float(mi))
+        for v in self.p.values():
+            v.grad = None
+        total.backward()
+        g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
+        self.enc_grad = torch.cat([g[k].reshape(-1) for k in self.enc_names]).clone()
+        self.dec_grad = torch.cat([g[k].reshape(-1) for k in self.dec_names]).clone()
+
+    def early_buckets(self):
+        return [self.dec_grad]
+
+    def late_buckets(self):
+        return [self.enc_grad]
+
+    def early_context(self):
+        return contextlib.nullcontext()
+
+    def apply_update(self):
+        params = {k: v.detach().numpy().copy() for k, v in self.p.items()}
+        grads = {}
+        for names, flat in ((self.enc_names, self.enc_grad), (self.dec_names, self.dec_grad)):
+            o = 0
+            for k in names:
+                n = params[k].size
+                grads[k] = flat[o:o + n].numpy().reshape(params[k].shape)
+                o += n
+        O.adam_update(params, grads, self.m, self.v, self.lr)
+        self.p = {k: torch.tensor(v, dtype=DT, requires_grad=True) for k, v in params.items()}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from arcvae_hip.dp import DataParallelStep
+    cfg, B, T = TINY, 6, 10
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    ops = OracleOps(cfg, params, x[sl], cond[sl], eps[sl], coins, T, 2e-4)
+    step = DataParallelStep(ops)
+    assert step.world == world
+    step.step()
+    out = {k: v.detach().numpy() for k, v in ops.p.items()}
+    if rank == 0:
+        ret["params"] = out
+        ret["scalars"] = ops.scalars
+        ret["enc_grad"] = ops.enc_grad.numpy()
+        ret["dec_grad"] = ops.dec_grad.numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_process_global_batch():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    cfg, B, T = TINY, 6, 10
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    vals, grads = O.loss_and_grads(p64, cfg, x, cond, eps, coins, dtype=DT, **HYPER)
+    sc = ret["scalars"]
+    assert abs(sc["total"] - float(vals["total_loss"])) < 1e-10
+    assert abs(sc["mi"] - float(vals["mutual_info"])) < 1e-10
+    enc_ref = np.concatenate([grads[k].reshape(-1) for k in params if k.startswith("encoder.")])
+    dec_ref = np.concatenate([grads[k].reshape(-1) for k in params if k.startswith("decoder.")])
+    assert np.abs(ret["enc_grad"] - enc_ref).max() < 1e-12
+    assert np.abs(ret["dec_grad"] - dec_ref).max() < 1e-12
+    m = {k: np.zeros_like(v) for k, v in p64.items()}
+    v = {k: np.zeros_like(vv) for k, vv in p64.items()}
+    O.adam_update(p64, grads, m, v, 2e-4)
+    for k in p64:
+        assert np.abs(ret["params"][k] - p64[k]).max() < 1e-10, k

@@ -1,0 +1,81 @@
+"""HIP path against the committed golden fixtures (tests/golden/*.npz; nothing under oracle/ or
+/root/reference is read here).  Tolerance 1e-4 relative (north_star), norm-wise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import arcvae_oracle as O  # only for init_params / synthetic_batch (seeded input regeneration)
+from helpers import DEFAULT, HYPER, SMALL, TINY, build_engine, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+def _run(cfg, name):
+    g = np.load(os.path.join(GOLD, name))
+    B, T, tf = (int(v) for v in g["meta"])
+    params, x, cond, eps, coins = make_case(cfg, B, T, tf / 1000.0)
+    eng, enc, dec = build_engine(cfg, params)
+    out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    return g, eng, enc, dec, out, (params, x, cond, eps, coins, B, T)
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_step.npz", TINY), ("small_step.npz", SMALL)])
+def test_full_fixture(name, cfg):
+    g, eng, enc, dec, out, (params, x, cond, eps, coins, B, T) = _run(cfg, name)
+    for k in ("total_loss", "recon_loss", "kl_loss", "weighted_kl", "collapse_penalty", "mutual_info", "mi_penalty"):
+        ref = float(g[f"val.{k}"])
+        assert abs(float(out[k]) - ref) <= TOL * max(1.0, abs(ref)), k
+    ws = eng.workspace(B, T)
+    assert np.array_equal(ws.fed.cpu().numpy(), g["val.fed_tokens"])
+    for k in ("mu", "logvar", "z"):
+        assert rel_err(out[k].cpu().numpy(), g[f"val.{k}"]) < TOL, k
+    assert rel_err(eng.gather_logits(ws).cpu().numpy(), g["val.logits"]) < TOL
+    for key in g.files:
+        if not key.startswith("grad."):
+            continue
+        mod, pname = key[5:].split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        ref = g[key]
+        if np.abs(ref).max() == 0:
+            assert np.abs(got).max() == 0, key
+        else:
+            assert rel_err(got, ref) < TOL, key
+    # one Adam step from zero state
+    eng.train_step(x, cond, eps, coins, lr=2e-4, update=True, **HYPER)
+    torch.cuda.synchronize()
+    for key in g.files:
+        if key.startswith("adam1."):
+            mod, pname = key[6:].split(".", 1)
+            got = (enc if mod == "encoder" else dec).p(pname).cpu().numpy()
+            assert rel_err(got, g[key]) < 1e-5, key
+
+
+def test_default_shape_digest():
+    g, eng, enc, dec, out, (params, x, cond, eps, coins, B, T) = _run(DEFAULT, "default_digest.npz")
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        ref = float(g[f"val.{k}"])
+        assert abs(float(out[k]) - ref) <= TOL * max(1.0, abs(ref)), k
+    ws = eng.workspace(B, T)
+    assert np.array_equal(ws.fed.cpu().numpy(), g["val.fed_tokens"])
+    assert rel_err(out["mu"].cpu().numpy(), g["val.mu"]) < TOL
+    assert rel_err(out["logvar"].cpu().numpy(), g["val.logvar"]) < TOL
+    logits = eng.gather_logits(ws).cpu().numpy().astype(np.float64)
+    assert np.abs(logits.sum(-1) - g["val.logits_rowsum"]).max() <= TOL * float(g["val.logits_absmax"]) * logits.shape[-1] ** 0.5
+    for key in g.files:
+        if not key.startswith("grow."):
+            continue
+        mod, pname = key[5:].split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy().astype(np.float64)
+        rows = got.reshape(got.shape[0], -1).sum(1)
+        s = g["gsum." + key[5:]]
+        if s[2] == 0:
+            assert np.abs(got).max() == 0, key
+            continue
+        width = got.size // got.shape[0]
+        assert np.abs(rows - g[key]).max() <= TOL * s[2] * max(1.0, width ** 0.5), key
+        assert abs(np.abs(got).sum() - s[1]) <= TOL * s[1], key
