@@ -107,8 +107,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-per-gpu", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", choices=["auto", "graph", "eager", "segments"], default="auto",
+                    help="launch mode: one multi-stream hipGraph, eager launches, or per-stream graph segments")
     ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel driver (process group + collectives) even at world size 1")
     args = ap.parse_args()
 
     import torch
@@ -129,8 +133,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if args.force_dp:
+            os.environ["ARCVAE_DP_FORCE_COLLECTIVES"] = "1"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.batch_per_gpu
@@ -142,7 +150,10 @@ def main():
     dec.init_mlx_like(H, gen)
     enc.p("fc_logvar.bias").fill_(0.35)
     eng = E.StepEngine(enc, dec, dims)
-    eng.use_graph = not args.no_graph
+    mode = args.mode
+    if mode == "auto":
+        mode = "eager" if args.no_graph else "segments"
+    eng.mode = mode
     ws = eng.workspace(B, T, train=True)
     eng.set_hyper(ws, **HYPER)
 
@@ -160,8 +171,8 @@ def main():
     coins = torch.tensor((crs.rand(total, T) < TF_RATIO).astype(np.uint8), device=dev)
 
     dp = None
-    if world > 1:
-        dp = DataParallelStep(EngineOps(eng, ws, LR, B * world, use_graph=eng.use_graph))
+    if use_dp:
+        dp = DataParallelStep(EngineOps(eng, ws, LR, B * world, use_graph=(mode != "eager")))
 
     def one_step(i):
         k = i % nbuf
@@ -174,7 +185,7 @@ def main():
         else:
             dp.step()
 
-    log(f"rank {rank}/{world}: warm-up ({args.warmup} steps, graph={eng.use_graph})")
+    log(f"rank {rank}/{world}: warm-up ({args.warmup} steps, mode={mode})")
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
@@ -183,8 +194,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_enq = 0.0
     for i in range(args.warmup, total):
+        h0 = time.perf_counter()
         one_step(i)
+        host_enq += time.perf_counter() - h0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -207,13 +221,13 @@ def main():
             "config": {"workload": "default AR-CVAE V80 E128 H256 Z128 C1 L2, bs 64/GPU, T 128, tf 0.9, "
                                    "beta 0 (epoch-0 schedule), fwd+bwd+Adam (BASELINE.json configs[1])",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "hip_graph": bool(eng.use_graph)},
+                       "launch_mode": mode},
             "elbo": {"total": float(scal[0]), "recon": float(scal[1]), "kl": float(scal[2]),
                      "mutual_info": float(scal[7])},
             "step_tflops_algorithmic": seqs * f_seq / 1e12,
             "step_frac_of_f32_mfma_peak": seqs * f_seq / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
         }
-        log(f"timed: {ms:.3f} ms/step, {seqs:.0f} seq/s")
+        log(f"timed: {ms:.3f} ms/step, {seqs:.0f} seq/s (host enqueue {1e3 * host_enq / args.steps:.3f} ms/step)")
         if not args.no_roofline:
             out["roofline"] = roofline_probe(eng, ws, torch)
             log("roofline probe done")
@@ -221,7 +235,7 @@ def main():
             log(f"cpu baseline on {host_cores()} host cores")
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -247,7 +261,7 @@ def roofline_probe(eng, ws, torch):
 
     def sweep():
         E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * d.H,
-               E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.wT), B, Tn, d.H, d.L, E.stream_ptr())
+               E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, Tn, d.H, d.L, 0, Tn + 2 * (d.L - 1), E.stream_ptr())
 
     g = torch.cuda.CUDAGraph()
     sweep()
@@ -261,7 +275,7 @@ def roofline_probe(eng, ws, torch):
         g.replay()
     e1.record(s)
     torch.cuda.synchronize()
-    launches = Tn + d.L - 1
+    launches = Tn + 2 * (d.L - 1)
     us = 1e3 * e0.elapsed_time(e1) / reps / launches
     jobs = d.L * Tn
     flops_total = 2.0 * B * 4 * d.H * d.H * (jobs - d.L + (d.L - 1) * Tn)  # Wh terms (t<T-1) + Wx_up terms

@@ -63,15 +63,20 @@ int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const floa
                             float* gseq, int B, int T, int V, int H, int L, arcvae_stream_t stream);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
- * position read by models/encoder.py:106.  dG out [L,T,B,4H]; dcs ws [L,T,B,H]; wT ws [(2L-1),H,4H]. */
+ * position read by models/encoder.py:106.  dG out [L,T,B,4H]; dcs, dxs ws [L,T,B,H]; wT ws [(2L-1),H,4H]. */
 int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                              const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
-                             float* wT, int B, int T, int H, int L, arcvae_stream_t stream);
-/* Parameter gradients of the stack from dG: embedding.weight, lstm_layer_l.{Wx,Wh,bias}. */
+                             float* dxs, float* wT, int B, int T, int H, int L, int s_begin, int s_end,
+                             arcvae_stream_t stream);
+/* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
+ *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
+ * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,
+ * lstm_layer_l.{Wx,Wh,bias}; `first` zeroes the token-table workspace, `last` folds it into the
+ * embedding / layer-0 gradients. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
                           const float* dG, float* dtable_ws, float* dEmb, float* const* dWx,
                           float* const* dWh, float* const* dbias, int B, int T, int V, int E, int H, int L,
-                          arcvae_stream_t stream);
+                          int t_lo, int t_hi, int first, int last, arcvae_stream_t stream);
 
 /* ---- encoder heads + reparameterisation + latent loss ----------------------------------------
  * models/encoder.py:106-130 (condition_fc, fc_mu, fc_logvar_hidden, fc_logvar, tanh bounds),
@@ -94,7 +99,7 @@ int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* 
                               const float* comb, const float* lh, const float* dmu_raw, const float* dlv_raw,
                               float* dlh, float* dcomb, float* dWc, float* dbc, float* dWmu, float* dbmu,
                               float* dWlh, float* dblh, float* dWlv, float* dblv, int B, int H, int Z, int C,
-                              arcvae_stream_t stream);
+                              int phase /* 0 both, 1 dcomb chain, 2 parameter gradients */, arcvae_stream_t stream);
 
 /* ---- stand-alone loss pieces (the reference's `losses` module called on arbitrary tensors) ----------
  * models/encoder.py:147-153; losses/kl.py:39-58 + losses/info.py:27-35 partial sums (krow [B] may
@@ -152,6 +157,7 @@ int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int rows, int n
 int arcvae_transpose_batched(const float* const* src, float* const* dst, const int* rows, const int* cols,
                              int n, arcvae_stream_t stream);
 int arcvae_scale_inplace(float* x, long n, float s, arcvae_stream_t stream);
+int arcvae_zero(float* x, int rows, int cols, int ld, arcvae_stream_t stream);
 
 #ifdef __cplusplus
 }

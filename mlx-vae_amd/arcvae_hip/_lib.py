@@ -33,12 +33,12 @@ SIGNATURES = {
     "arcvae_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp],
     "arcvae_transpose_tokens": [_vp, _vp, _i, _i, _vp],
     "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _vp],
+    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _vp],
     "arcvae_stats_set_recon": [_vp, _i, _vp, _i, _vp],
     "arcvae_latent_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
-    "arcvae_enc_heads_backward": [_vp] * 18 + [_i, _i, _i, _i, _vp],
+    "arcvae_enc_heads_backward": [_vp] * 18 + [_i, _i, _i, _i, _i, _vp],
     "arcvae_dec_forward_dense": [_vp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "arcvae_dec_chain_ce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -56,6 +56,7 @@ SIGNATURES = {
     "arcvae_segsum_rows_accum": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "arcvae_transpose_batched": [_pp, _pp, _ip, _ip, _i, _vp],
     "arcvae_scale_inplace": [_vp, _l, _f, _vp],
+    "arcvae_zero": [_vp, _i, _i, _i, _vp],
 }
 
 _lib: Optional[C.CDLL] = None

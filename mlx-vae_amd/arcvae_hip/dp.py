@@ -72,93 +72,32 @@ class DataParallelStep:
 
 
 class EngineOps:
-    """StepOps over the HIP StepEngine: per-stream hipGraph segments with the collectives between.
+    """StepOps over the HIP StepEngine (engine.py): the engine's three phases with the collectives between.
 
-    side stream : [dec_fwd graph] -> ev_chain -> [dec_bwd graph] -> ev_dec_bwd
-    main stream : [enc_fwd graph] -> wait ev_chain -> set_recon -> (all-reduce stats)
-                  -> [enc_bwd graph] -> (all-reduce enc.grad) -> Adam x2
+    side stream : [dec_fwd] -> ev_chain -> [dec_bwd] -> ev_dec_bwd
+    main stream : [enc_fwd] -> wait ev_chain -> [recon] -> (all-reduce stats)
+                  -> [loss][heads1][sweep chunks...] -> (all-reduce enc.grad) -> [adam]
+    aux stream  : [heads2][wgrad chunks...] behind the sweep
     comm stream : wait ev_dec_bwd -> (all-reduce dec.grad), overlapping the encoder BPTT
     """
 
     def __init__(self, engine, ws, lr: float, global_rows: int, use_graph: bool = True):
-        from . import engine as E
-        self.E = E
         self.eng, self.ws, self.lr = engine, ws, float(lr)
         self.global_rows = int(global_rows)
         self.stats = ws.stats
-        self.use_graph = use_graph
-        self._g = {}
+        self.run = engine.runner(ws, lr, global_rows, capture=use_graph)
         self.comm = torch.cuda.Stream(device=engine.device)
-        self._ev_chain = torch.cuda.Event()
-        self._ev_dec_bwd = torch.cuda.Event()
 
-    def _run(self, key: str, fn, stream: torch.cuda.Stream) -> None:
-        """Run `fn` on `stream`; captured once into a hipGraph (a single-stream segment)."""
-        with torch.cuda.stream(stream):
-            if not self.use_graph:
-                fn()
-                return
-            g = self._g.get(key)
-            if g is None:
-                fn()  # first step runs eagerly (its results are this step's results) ...
-                stream.synchronize()
-                try:  # ... and is then recorded for replay from the next step on
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                        fn()
-                    self._g[key] = g
-                except Exception as exc:  # keep training eagerly if capture is refused
-                    print(f"[arcvae_hip.dp] graph capture of segment {key!r} failed ({exc}); running eagerly")
-                    torch.cuda.synchronize()
-                    self._g[key] = False
-                return
-            if g is False:
-                fn()
-            else:
-                g.replay()
-
-    # -- StepOps ------------------------------------------------------------------------------------
     def forward_local(self) -> None:
-        E, eng, ws, d = self.E, self.eng, self.ws, self.eng.d
-        main = torch.cuda.current_stream()
-        fb = float(eng.hyper_host["free_bits"])
-        eng.side.wait_stream(main)
-
-        def dec_fwd():
-            eng.dec.grad.zero_()
-            E.decoder_forward_dense(eng.dec, ws, d)
-            E.decoder_chain(ws, d)
-
-        def dec_bwd():
-            E.decoder_backward(eng.dec, ws, d, 1.0 / (self.global_rows * ws.T))
-
-        def enc_fwd():
-            eng.enc.grad.zero_()
-            E.encoder_forward(eng.enc, ws, d, fb)
-
-        self._run("dec_fwd", dec_fwd, eng.side)
-        self._ev_chain.record(eng.side)
-        # the decoder backward does not depend on the stats seam: keep the side stream busy
-        self._run("dec_bwd", dec_bwd, eng.side)
-        self._ev_dec_bwd.record(eng.side)
-        self._run("enc_fwd", enc_fwd, main)
-        main.wait_event(self._ev_chain)
-        E.call("arcvae_stats_set_recon", E.ptr(ws.rowloss), ws.B, E.ptr(ws.stats), d.Z, E.stream_ptr())
+        self.eng.enqueue_forward(self.ws, self.global_rows, self.run)
 
     def backward_local(self) -> None:
-        E, eng, ws, d = self.E, self.eng, self.ws, self.eng.d
-        fb = float(eng.hyper_host["free_bits"])
-
-        def enc_bwd():
-            E.latent_loss(ws, d, fb, True)
-            E.encoder_backward(eng.enc, ws, d)
-
-        self._run("enc_bwd", enc_bwd, torch.cuda.current_stream())
+        self.eng.enqueue_backward(self.ws, self.run)
 
     @contextlib.contextmanager
     def early_context(self):
         # issue the decoder-bucket reduce from the comm stream so it does not queue behind BPTT
-        self.comm.wait_event(self._ev_dec_bwd)
+        self.comm.wait_event(self.eng.ev_dec_bwd)
         with torch.cuda.stream(self.comm):
             yield
 
@@ -169,9 +108,5 @@ class EngineOps:
         return [self.eng.enc.grad]
 
     def apply_update(self) -> None:
-        E, eng = self.E, self.eng
-        main = torch.cuda.current_stream()
-        main.wait_stream(eng.side)
-        main.wait_stream(self.comm)
-        E.adam_update(eng.dec, self.lr)
-        E.adam_update(eng.enc, self.lr)
+        torch.cuda.current_stream().wait_stream(self.comm)
+        self.eng.enqueue_update(self.lr, self.run)

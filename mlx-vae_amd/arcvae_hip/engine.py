@@ -5,13 +5,14 @@ models/encoder.py:76-155, models/decoder.py:113-190, losses/{recon,kl,info}.py, 
 MLX Adam updates.  Here the same step is a fixed sequence of launches on two HIP streams:
 
   main stream : tokens^T -> table0 GEMM -> LSTM wavefront sweep -> heads -> [stats seam]
-                -> latent loss -> heads bwd -> BPTT wavefront -> weight-grad GEMMs -> Adam(enc)
+                -> latent loss -> heads dcomb chain -> BPTT wavefront -> Adam
   side stream : dense decoder fwd (B*V rows) -> TF walk + CE -> dlogits -> dense decoder bwd
-                -> Adam(dec)
+  aux stream  : parameter-gradient GEMMs of the encoder, chunk by chunk behind the BPTT sweep
 
-The decoder never reads z, so the two streams only meet at the loss scalars.  The
-whole single-GPU step is captured once per (B,T) shape into a hipGraph and replayed; inputs,
-teacher-forcing coins and the epoch-scheduled hyper-parameters live in static device buffers.
+The decoder never reads z, so the streams only meet at the loss scalars.  Each
+stream's launch sequence is captured once per (B,T) shape into linear hipGraph segments and
+replayed; inputs, teacher-forcing coins and the epoch-scheduled hyper-parameters live in static
+device buffers.
 
 Nothing here computes on the CPU and nothing falls back to PyTorch ops for the math: torch is
 used for device memory, streams, graphs and (in dp.py) torch.distributed/RCCL.
@@ -100,6 +101,7 @@ class Workspace:
             self.dcomb = torch.empty(B, 2 * H, **f32)
             self.dG = torch.empty(L, T, B, G, **f32)
             self.dcs = torch.empty(L, T, B, H, **f32)
+            self.dxs = torch.empty(L, T, B, H, **f32)
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
             self.dtable0 = torch.empty(V, G, **f32)
             self.dlogits = torch.empty(BV, V, **f32)
@@ -178,26 +180,106 @@ def latent_loss(ws: Workspace, d: ModelDims, free_bits: float, with_grads: bool)
          ws.B, d.Z, ws.T, float(free_bits), stream_ptr())
 
 
-def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims) -> None:
-    B, T = ws.B, ws.T
-    s = stream_ptr()
-    call("arcvae_enc_heads_backward", ptr(ws.cond), ptr(enc.p("fc_mu.weight")),
-         ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar.weight")), ptr(ws.comb), ptr(ws.lh),
-         ptr(ws.dmu_raw), ptr(ws.dlv_raw), ptr(ws.dlh), ptr(ws.dcomb), ptr(enc.g("condition_fc.weight")),
-         ptr(enc.g("condition_fc.bias")), ptr(enc.g("fc_mu.weight")), ptr(enc.g("fc_mu.bias")),
-         ptr(enc.g("fc_logvar_hidden.weight")), ptr(enc.g("fc_logvar_hidden.bias")),
-         ptr(enc.g("fc_logvar.weight")), ptr(enc.g("fc_logvar.bias")), B, d.H, d.Z, d.C, s)
-    wx, _k1 = _layer_ptrs(enc, d.L, "Wx", skip0=True)
-    wh, _k2 = _layer_ptrs(enc, d.L, "Wh")
-    # d/d(hT) = dcomb[:, :H]  (row stride 2H)
-    call("arcvae_enc_lstm_backward", wx, wh, ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG),
-         ptr(ws.dcs), ptr(ws.wT), B, T, d.H, d.L, s)
-    dwx, _k3 = _layer_ptrs(enc, d.L, "Wx", grad=True)
-    dwh, _k4 = _layer_ptrs(enc, d.L, "Wh", grad=True)
-    dbs, _k5 = _layer_ptrs(enc, d.L, "bias", grad=True)
-    call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
-         ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(enc.g("embedding.weight")), dwx, dwh, dbs, B, T, d.V,
-         d.E, d.H, d.L, s)
+def _inline(key, fn, stream) -> None:
+    with torch.cuda.stream(stream):
+        fn()
+
+
+class SegmentRunner:
+    """Runs named launch sequences on given streams -- eagerly, or captured ONCE each as a single-stream
+    hipGraph and replayed.  Single-stream (linear) segments with eager events between them are used instead
+    of one forked multi-stream graph: on ROCm 7.2 a forked hipGraph starts its second branch only when the
+    first reaches the join (profiles/r01_graph_vs_segments), which serialises decoder and encoder."""
+
+    def __init__(self, capture: bool):
+        self.capture = capture
+        self._g: Dict[str, object] = {}
+        self._cap_stream: Optional[torch.cuda.Stream] = None  # capture may not happen on the default stream
+
+    def __call__(self, key: str, fn, stream: torch.cuda.Stream) -> None:
+        with torch.cuda.stream(stream):
+            if not self.capture:
+                fn()
+                return
+            g = self._g.get(key)
+            if g is None:
+                fn()  # first step runs eagerly (its results are this step's results) ...
+                stream.synchronize()
+                try:  # ... and is then recorded (on a private stream) for replay from the next step on
+                    if self._cap_stream is None:
+                        self._cap_stream = torch.cuda.Stream(device=stream.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode="thread_local"):
+                        fn()
+                    self._g[key] = g
+                except Exception as exc:  # keep training eagerly if capture is refused
+                    print(f"[arcvae_hip] graph capture of segment {key!r} failed ({exc}); running it eagerly")
+                    torch.cuda.synchronize()
+                    self._g[key] = False
+            elif g is False:
+                fn()
+            else:
+                g.replay()
+
+
+def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
+                     nchunks: int = 4, run=_inline) -> None:
+    """Backward of heads + LSTM stack.  Critical path on the current stream: dcomb chain -> BPTT wavefront.
+    With `aux`, everything that only produces parameter gradients (heads' weight grads, then the LSTM
+    weight-gradient GEMMs chunk by chunk as the sweep releases time ranges) runs on that stream, overlapped
+    with the sweep; the current stream joins `aux` before returning.  `run(key, fn, stream)` executes one
+    single-stream segment (inline, or through a SegmentRunner)."""
+    B, T, L = ws.B, ws.T, d.L
+    main = torch.cuda.current_stream()
+
+    def heads(phase):
+        call("arcvae_enc_heads_backward", ptr(ws.cond), ptr(enc.p("fc_mu.weight")),
+             ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar.weight")), ptr(ws.comb), ptr(ws.lh),
+             ptr(ws.dmu_raw), ptr(ws.dlv_raw), ptr(ws.dlh), ptr(ws.dcomb), ptr(enc.g("condition_fc.weight")),
+             ptr(enc.g("condition_fc.bias")), ptr(enc.g("fc_mu.weight")), ptr(enc.g("fc_mu.bias")),
+             ptr(enc.g("fc_logvar_hidden.weight")), ptr(enc.g("fc_logvar_hidden.bias")),
+             ptr(enc.g("fc_logvar.weight")), ptr(enc.g("fc_logvar.bias")), B, d.H, d.Z, d.C, phase, stream_ptr())
+
+    wx, _k1 = _layer_ptrs(enc, L, "Wx", skip0=True)
+    wh, _k2 = _layer_ptrs(enc, L, "Wh")
+    dwx, _k3 = _layer_ptrs(enc, L, "Wx", grad=True)
+    dwh, _k4 = _layer_ptrs(enc, L, "Wh", grad=True)
+    dbs, _k5 = _layer_ptrs(enc, L, "bias", grad=True)
+
+    def sweep(s0, s1):  # d/d(hT) = dcomb[:, :H] (row stride 2H)
+        call("arcvae_enc_lstm_backward", wx, wh, ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG),
+             ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), B, T, d.H, L, s0, s1, stream_ptr())
+
+    def wgrad(t_lo, t_hi, first, last):
+        call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
+             ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(enc.g("embedding.weight")), dwx, dwh, dbs, B, T, d.V,
+             d.E, d.H, L, t_lo, t_hi, int(first), int(last), stream_ptr())
+
+    S = T + 2 * (L - 1)  # launches of the BPTT wavefront (csrc/lstm.hip)
+    if aux is None:
+        run("enc_bwd_all", lambda: (heads(0), sweep(0, S), wgrad(0, T, True, True)), main)
+        return
+    run("heads1", lambda: heads(1), main)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    aux.wait_event(ev)
+    run("heads2", lambda: heads(2), aux)
+    nchunks = max(1, min(nchunks, S))
+    bounds = [round(i * S / nchunks) for i in range(nchunks + 1)]
+    t_hi = T
+    for c in range(nchunks):
+        s0, s1 = bounds[c], bounds[c + 1]
+        if s1 <= s0:
+            continue
+        run(f"sweep{c}", lambda s0=s0, s1=s1: sweep(s0, s1), main)
+        # after launches [0, s1) every layer has finished all t >= T - s1 + 2(L-1)
+        t_lo = 0 if s1 >= S else min(T, max(0, T - s1 + 2 * (L - 1)))
+        evc = torch.cuda.Event()
+        evc.record(main)
+        aux.wait_event(evc)
+        run(f"wgrad{c}", lambda a=t_lo, b=t_hi, f=(t_hi == T), l=(s1 >= S): wgrad(a, b, f, l), aux)
+        t_hi = t_lo
+    main.wait_stream(aux)
 
 
 def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
@@ -208,7 +290,13 @@ def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999
 
 # --------------------------------------------------------------------------------------------
 class StepEngine:
-    """Owns workspaces, the side stream and the captured step graph for one (encoder, decoder) pair."""
+    """Owns workspaces, streams and captured launch segments for one (encoder, decoder) pair.
+
+    Streams:  main (caller's current stream): encoder forward -> loss -> BPTT (the critical chain)
+              side: dense decoder forward/backward (+ its Adam)        aux: parameter-gradient GEMMs
+    `mode`:   "segments" (default) per-stream linear hipGraph segments with eager events between them;
+              "eager" plain launches; "graph" the whole step as ONE forked hipGraph (kept for comparison).
+    """
 
     def __init__(self, enc: ParamStore, dec: ParamStore, dims: ModelDims):
         dims.validate()
@@ -217,9 +305,22 @@ class StepEngine:
         self.device = enc.device
         self._ws: Dict[Tuple[int, int, bool], Workspace] = {}
         self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
+        self._runners: Dict[Tuple, SegmentRunner] = {}
         self.side = torch.cuda.Stream(device=self.device)
+        self.aux = torch.cuda.Stream(device=self.device)
         self.hyper_host = dict(beta=0.4, lambda_collapse=0.01, lambda_mi=0.0, target_mi=4.85, free_bits=0.5)
-        self.use_graph = True
+        self.mode = "segments"
+        self.ev_chain = torch.cuda.Event()
+        self.ev_dec_bwd = torch.cuda.Event()
+
+    # `use_graph` is the older boolean switch: True -> captured segments, False -> eager launches
+    @property
+    def use_graph(self) -> bool:
+        return self.mode != "eager"
+
+    @use_graph.setter
+    def use_graph(self, v: bool) -> None:
+        self.mode = "segments" if v else "eager"
 
     # ---- buffers ----------------------------------------------------------------------------
     def workspace(self, B: int, T: int, train: bool = True) -> Workspace:
@@ -243,9 +344,8 @@ class StepEngine:
         dev = self.device
         xt = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x)
         ws.x.copy_(xt.to(device=dev, dtype=torch.int32))
-        if self.d.C:
-            ct = torch.as_tensor(np.asarray(cond) if not isinstance(cond, torch.Tensor) else cond)
-            ws.cond.copy_(ct.to(device=dev, dtype=torch.float32).reshape(ws.B, self.d.C))
+        ct = torch.as_tensor(np.asarray(cond) if not isinstance(cond, torch.Tensor) else cond)
+        ws.cond.copy_(ct.to(device=dev, dtype=torch.float32).reshape(ws.B, self.d.C))
         if eps is not None:
             et = torch.as_tensor(np.asarray(eps) if not isinstance(eps, torch.Tensor) else eps)
             ws.eps.copy_(et.to(device=dev, dtype=torch.float32))
@@ -253,40 +353,61 @@ class StepEngine:
             ck = torch.as_tensor(np.asarray(coins).astype(np.uint8))
             ws.coins.copy_(ck.to(dev))
 
-    # ---- launch sequences -----------------------------------------------------------------------
-    def _enqueue_forward(self, ws: Workspace, free_bits: float) -> None:
-        main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            decoder_forward_dense(self.dec, ws, self.d)
-            decoder_chain(ws, self.d)
-        encoder_forward(self.enc, ws, self.d, free_bits)
+    def runner(self, ws: Workspace, lr: float, global_rows: int, capture: bool) -> SegmentRunner:
+        key = (ws.B, ws.T, float(lr), float(self.hyper_host["free_bits"]), int(global_rows), bool(capture))
+        if key not in self._runners:
+            self._runners[key] = SegmentRunner(capture)
+        return self._runners[key]
 
-    def _enqueue_loss(self, ws: Workspace, free_bits: float, with_grads: bool) -> None:
-        call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z, stream_ptr())
-        latent_loss(ws, self.d, free_bits, with_grads)
-
-    def _enqueue_step(self, ws: Workspace, lr: float, free_bits: float, global_rows: int, update: bool) -> None:
-        """Whole single-process step on (current stream, side stream)."""
+    # ---- the three phases of a step (data-parallel collectives go between them, dp.py) ------------------
+    def enqueue_forward(self, ws: Workspace, global_rows: int, run=_inline, backward: bool = True) -> None:
+        """encoder forward on main, dense decoder (+ its backward) on side; on return main holds this
+        process's partial `stats` (complete once ev_chain has been waited for)."""
         main = torch.cuda.current_stream()
-        self.enc.grad.zero_()
+        fb = float(self.hyper_host["free_bits"])
+        d = self.d
         self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            self.dec.grad.zero_()
-            decoder_forward_dense(self.dec, ws, self.d)
-            decoder_chain(ws, self.d)
-            ev_chain = torch.cuda.Event()
-            ev_chain.record(self.side)
-            decoder_backward(self.dec, ws, self.d, 1.0 / (global_rows * ws.T))
-            if update:
-                adam_update(self.dec, lr)
-        encoder_forward(self.enc, ws, self.d, free_bits)
-        main.wait_event(ev_chain)
-        self._enqueue_loss(ws, free_bits, True)
-        encoder_backward(self.enc, ws, self.d)
-        if update:
-            adam_update(self.enc, lr)
+
+        def enc_fwd():
+            if backward:
+                self.enc.grad.zero_()
+            encoder_forward(self.enc, ws, d, fb)
+
+        def dec_fwd():
+            if backward:
+                self.dec.grad.zero_()
+            decoder_forward_dense(self.dec, ws, d)
+            decoder_chain(ws, d)
+
+        run("enc_fwd", enc_fwd, main)  # the critical chain is enqueued first
+        run("dec_fwd", dec_fwd, self.side)
+        self.ev_chain.record(self.side)
+        if backward:  # does not depend on the stats seam: keep the side stream busy
+            run("dec_bwd", lambda: decoder_backward(self.dec, ws, d, 1.0 / (global_rows * ws.T)), self.side)
+            self.ev_dec_bwd.record(self.side)
+        main.wait_event(self.ev_chain)
+        run("recon", lambda: call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), d.Z, stream_ptr()),
+            main)
+
+    def enqueue_backward(self, ws: Workspace, run=_inline) -> None:
+        """`stats` now holds GLOBAL sums: loss scalars, latent gradients, encoder backward."""
+        fb = float(self.hyper_host["free_bits"])
+        main = torch.cuda.current_stream()
+        run("loss", lambda: latent_loss(ws, self.d, fb, True), main)
+        encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run)
+
+    def enqueue_update(self, lr: float, run=_inline) -> None:
+        main = torch.cuda.current_stream()
         main.wait_stream(self.side)
+        run("adam", lambda: (adam_update(self.dec, lr), adam_update(self.enc, lr)), main)
+
+    def _enqueue_step(self, ws: Workspace, lr: float, global_rows: int, update: bool, run=_inline) -> None:
+        self.enqueue_forward(ws, global_rows, run)
+        self.enqueue_backward(ws, run)
+        if update:
+            self.enqueue_update(lr, run)
+        else:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     # ---- public API --------------------------------------------------------------------------------
     def forward_loss(self, x, cond, eps, coins, **hyper) -> Dict[str, torch.Tensor]:
@@ -295,10 +416,8 @@ class StepEngine:
         ws = self.workspace(B, T, train=False)
         self.set_hyper(ws, **hyper)
         self.load_inputs(ws, x, cond, eps, coins)
-        fb = self.hyper_host["free_bits"]
-        self._enqueue_forward(ws, fb)
-        torch.cuda.current_stream().wait_stream(self.side)
-        self._enqueue_loss(ws, fb, False)
+        self.enqueue_forward(ws, B, backward=False)
+        latent_loss(ws, self.d, float(self.hyper_host["free_bits"]), False)
         return self._results(ws)
 
     def train_step(self, x, cond, eps, coins, lr: float, update: bool = True, **hyper) -> Dict[str, torch.Tensor]:
@@ -312,21 +431,22 @@ class StepEngine:
 
     def run_step(self, ws: Workspace, lr: float, update: bool = True) -> None:
         """Enqueue (or replay) the step on the current stream; inputs/hyper already in `ws`."""
-        fb = float(self.hyper_host["free_bits"])
-        key = (ws.B, ws.T, float(lr), fb, bool(update))
-        if not self.use_graph:
-            self._enqueue_step(ws, lr, fb, ws.B, update)
+        if self.mode == "graph":
+            key = (ws.B, ws.T, float(lr), float(self.hyper_host["free_bits"]), bool(update))
+            g = self._graphs.get(key)
+            if g is None:
+                self._enqueue_step(ws, lr, ws.B, False)  # warm-up once eagerly, then capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_step(ws, lr, ws.B, update)
+                self._graphs[key] = g
+            g.replay()
             return
-        g = self._graphs.get(key)
-        if g is None:
-            # warm-up once eagerly (module load, allocator), then capture
-            self._enqueue_step(ws, lr, fb, ws.B, False)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._enqueue_step(ws, lr, fb, ws.B, update)
-            self._graphs[key] = g
-        g.replay()
+        run = self.runner(ws, lr, ws.B, capture=(self.mode == "segments"))
+        if not update:  # gradient-only steps (tests, value_and_grad without lr) use their own segment set
+            run = self.runner(ws, -1.0, ws.B, capture=(self.mode == "segments"))
+        self._enqueue_step(ws, lr, ws.B, update, run)
 
     def _results(self, ws: Workspace) -> Dict[str, torch.Tensor]:
         out = {k: ws.scalars[i] for i, k in enumerate(SCALAR_KEYS)}

@@ -15,7 +15,7 @@
 //     split-K over gridDim.z with f32 atomics for the K-long / small-MN weight-gradient shapes.
 //   * skinny kernel (skinny.h): 16x16 tile per block, K split over the 4 waves -- used when M is
 //     a minibatch (<= 256 rows) and the op is on the step's critical path.
-#include "common.h"
+#include "ops.h"
 #include "skinny.h"
 
 namespace {
@@ -238,11 +238,6 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-#define ARCVAE_GEMM_ACCUMULATE 1
-#define ARCVAE_GEMM_TANH 2
-#define ARCVAE_GEMM_SPLITK 4
-#define ARCVAE_GEMM_NO_SKINNY 8
-
 extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
                                const float* A, int lda, const float* B, int ldb,
                                float* C, int ldc, const float* bias, int flags, hipStream_t stream) {
@@ -283,8 +278,7 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
             z = ceil_div(K, p.kchunk);
             grid.z = z;
             if (!p.accumulate) {
-                if (hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, stream) != hipSuccess)
-                    return ARCVAE_ERR_LAUNCH;
+                if (arcvae_zero(C, M, N, ldc, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
             }
         }
     }

@@ -200,7 +200,7 @@ extern "C" int arcvae_enc_heads_forward(const float* hT, const float* cond, cons
     if (rc) return rc;
     rc = arcvae_gemm_f32(0, 1, B, Z, H2, lh, H2, Wlv, H2, lv_raw, Z, blv, 0, stream);
     if (rc) return rc;
-    if (hipMemsetAsync(stats, 0, (size_t)(2 * Z + 4) * sizeof(float), stream) != hipSuccess) return ARCVAE_ERR_LAUNCH;
+    if (arcvae_zero(stats, 1, 2 * Z + 4, 2 * Z + 4, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
     const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
     hipLaunchKernelGGL(latent_apply_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, mu_raw, lv_raw, eps, mu,
                        logvar, z, stats, B, Z, fb_min);
@@ -229,37 +229,41 @@ extern "C" int arcvae_latent_loss(const float* stats, const float* hyper, const 
     return arcvae_launch_status();
 }
 
-// Backward of the heads: parameter gradients ("+=") and dcomb [B,2H] (its first H columns are
-// d/d(hT), consumed by arcvae_enc_lstm_backward with ld = 2H).   ws: dlh [B,2H]
+// Backward of the heads in two phases so the critical path (dcomb -> BPTT) does not wait for the
+// parameter-gradient GEMMs:
+//   phase 1: dcomb [B,2H] = dmu_raw . Wmu + (dlv_raw . Wlv * (1 - lh^2)) . Wlh ; leaves dlh = d(pre-tanh) in ws
+//            (dcomb's first H columns are d/d(hT), consumed by arcvae_enc_lstm_backward with ld = 2H)
+//   phase 2: parameter gradients ("+=") from dmu_raw, dlv_raw, dlh, dcomb  -- any stream, after phase 1
 extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* Wlh, const float* Wlv,
                                          const float* comb, const float* lh, const float* dmu_raw,
                                          const float* dlv_raw, float* dlh, float* dcomb, float* dWc, float* dbc,
                                          float* dWmu, float* dbmu, float* dWlh, float* dblh, float* dWlv,
-                                         float* dblv, int B, int H, int Z, int C, hipStream_t stream) {
+                                         float* dblv, int B, int H, int Z, int C, int phase, hipStream_t stream) {
     if (!cond || !Wmu || !Wlh || !Wlv || !comb || !lh || !dmu_raw || !dlv_raw || !dlh || !dcomb || !dWc || !dbc ||
         !dWmu || !dbmu || !dWlh || !dblh || !dWlv || !dblv)
         return ARCVAE_ERR_ARG;
+    if (phase < 0 || phase > 2) return ARCVAE_ERR_ARG;  // 0 = both
     const int H2 = 2 * H;
     const int ACC = ARCVAE_GEMM_ACCUMULATE;
     int rc;
-    // fc_mu
-    if ((rc = arcvae_gemm_f32(1, 0, Z, H2, B, dmu_raw, Z, comb, H2, dWmu, H2, nullptr, ACC, stream))) return rc;
-    if ((rc = arcvae_colsum_accum(dmu_raw, B, Z, Z, dbmu, 1.0f, stream))) return rc;
-    if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dmu_raw, Z, Wmu, H2, dcomb, H2, nullptr, 0, stream))) return rc;
-    // fc_logvar
-    if ((rc = arcvae_gemm_f32(1, 0, Z, H2, B, dlv_raw, Z, lh, H2, dWlv, H2, nullptr, ACC, stream))) return rc;
-    if ((rc = arcvae_colsum_accum(dlv_raw, B, Z, Z, dblv, 1.0f, stream))) return rc;
-    if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dlv_raw, Z, Wlv, H2, dlh, H2, nullptr, 0, stream))) return rc;
-    // tanh(fc_logvar_hidden)
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, lh, dlh, (long)B * H2);
-    if ((rc = arcvae_gemm_f32(1, 0, H2, H2, B, dlh, H2, comb, H2, dWlh, H2, nullptr, ACC, stream))) return rc;
-    if ((rc = arcvae_colsum_accum(dlh, B, H2, H2, dblh, 1.0f, stream))) return rc;
-    if ((rc = arcvae_gemm_f32(0, 0, B, H2, H2, dlh, H2, Wlh, H2, dcomb, H2, nullptr, ACC, stream))) return rc;
-    // condition_fc: dcr = dcomb[:, H:]
-    if (C > 0) {
-        if ((rc = arcvae_gemm_f32(1, 0, H, C, B, dcomb + H, H2, cond, C, dWc, C, nullptr, ACC, stream))) return rc;
+    if (phase == 0 || phase == 1) {
+        if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dmu_raw, Z, Wmu, H2, dcomb, H2, nullptr, 0, stream))) return rc;
+        if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dlv_raw, Z, Wlv, H2, dlh, H2, nullptr, 0, stream))) return rc;
+        hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, lh, dlh, (long)B * H2);
+        if ((rc = arcvae_gemm_f32(0, 0, B, H2, H2, dlh, H2, Wlh, H2, dcomb, H2, nullptr, ACC, stream))) return rc;
     }
-    if ((rc = arcvae_colsum_accum(dcomb + H, B, H, H2, dbc, 1.0f, stream))) return rc;
+    if (phase == 0 || phase == 2) {
+        if ((rc = arcvae_gemm_f32(1, 0, Z, H2, B, dmu_raw, Z, comb, H2, dWmu, H2, nullptr, ACC, stream))) return rc;
+        if ((rc = arcvae_colsum_accum(dmu_raw, B, Z, Z, dbmu, 1.0f, stream))) return rc;
+        if ((rc = arcvae_gemm_f32(1, 0, Z, H2, B, dlv_raw, Z, lh, H2, dWlv, H2, nullptr, ACC, stream))) return rc;
+        if ((rc = arcvae_colsum_accum(dlv_raw, B, Z, Z, dblv, 1.0f, stream))) return rc;
+        if ((rc = arcvae_gemm_f32(1, 0, H2, H2, B, dlh, H2, comb, H2, dWlh, H2, nullptr, ACC, stream))) return rc;
+        if ((rc = arcvae_colsum_accum(dlh, B, H2, H2, dblh, 1.0f, stream))) return rc;
+        if (C > 0) {  // condition_fc: dcr = dcomb[:, H:]
+            if ((rc = arcvae_gemm_f32(1, 0, H, C, B, dcomb + H, H2, cond, C, dWc, C, nullptr, ACC, stream))) return rc;
+        }
+        if ((rc = arcvae_colsum_accum(dcomb + H, B, H, H2, dbc, 1.0f, stream))) return rc;
+    }
     return arcvae_launch_status();
 }
 
@@ -349,7 +353,7 @@ extern "C" int arcvae_reparameterize(const float* mu, const float* logvar, const
 extern "C" int arcvae_latent_stats(const float* mu, const float* logvar, float* stats, float* krow, int B, int Z,
                                    float free_bits, hipStream_t stream) {
     if (!mu || !logvar || !stats || B <= 0 || Z <= 0) return ARCVAE_ERR_ARG;
-    if (hipMemsetAsync(stats, 0, (size_t)(2 * Z + 4) * sizeof(float), stream) != hipSuccess) return ARCVAE_ERR_LAUNCH;
+    if (arcvae_zero(stats, 1, 2 * Z + 4, 2 * Z + 4, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
     const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
     hipLaunchKernelGGL(latent_stats_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, mu, logvar, stats, krow, B, Z,
                        fb_min);

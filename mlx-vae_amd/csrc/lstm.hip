@@ -54,6 +54,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     const int jc = lane & 15;
     const long wrow = (long)(jc >> 2) * H + u0 + (jc & 3);  // gate-major weight row of tile column jc
     const bool s1 = j.xin != nullptr, s2 = j.hprev != nullptr;
+    // Epilogue operands are requested FIRST (token -> table row is a dependent pair of loads, c_{t-1}
+    // another cold line): their round trip then overlaps the operand loads instead of following the MFMAs.
+    const int erow = tid >> 4, ecol = tid & 15;
+    const int eb = min(r0 + erow, B - 1);
+    const int gcol = (ecol >> 2) * H + u0 + (ecol & 3);
+    const float* pre = j.pre;
+    if (j.tok) {
+        int tk = j.tok[eb];
+        tk = min(max(tk, 0), a.V - 1);
+        pre += (long)tk * 4 * H;
+    }
+    const float pre_v = pre[gcol];
+    const int crow = tid >> 2, cu = tid & 3;  // cell-update role of threads 0..63
+    const long hb = (long)min(r0 + crow, B - 1) * H + u0 + cu;
+    float cprev_v = 0.f;
+    if (tid < 64 && j.cprev) cprev_v = j.cprev[hb];
     SkinnyFrag<CH> f1, f2;
     if (s1) skinny_load<CH>(f1, j.xin, (long)arow * H, j.Wx, wrow * H, wave, lane);
     if (s2) skinny_load<CH>(f2, j.hprev, (long)arow * H, j.Wh, wrow * H, wave, lane);
@@ -63,58 +79,48 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     skinny_store_partial_n(red, acc0, acc1, wave, lane);
     __syncthreads();
     {   // one gate activation per thread: (row, col) -> gate = col>>2, unit = u0 + (col&3)
-        const int row = tid >> 4, col = tid & 15;
-        const int b = r0 + row;
-        if (b < B) {
-            const int gcol = (col >> 2) * H + u0 + (col & 3);
-            const float* pre = j.pre;
-            if (j.tok) {
-                int tk = j.tok[b];
-                tk = min(max(tk, 0), a.V - 1);
-                pre += (long)tk * 4 * H;
-            }
-            const float v = skinny_reduced_n<4>(red, row, col) + pre[gcol];
-            const float av = ((col >> 2) == 2) ? tanhf(v) : sigmoidf_acc(v);
-            act[tid] = av;
-            j.gates[(long)b * 4 * H + gcol] = av;
-        }
+        const float v = skinny_reduced_n<4>(red, erow, ecol) + pre_v;
+        const float av = ((ecol >> 2) == 2) ? tanhf(v) : sigmoidf_acc(v);
+        act[tid] = av;
+        if (r0 + erow < B) j.gates[(long)(r0 + erow) * 4 * H + gcol] = av;
     }
     __syncthreads();
-    if (tid < 64) {
-        const int row = tid >> 2, u = tid & 3;
-        const int b = r0 + row;
-        if (b < B) {
-            const float i = act[row * 16 + u], f = act[row * 16 + 4 + u], g = act[row * 16 + 8 + u],
-                        o = act[row * 16 + 12 + u];
-            const long hb = (long)b * H + u0 + u;
-            const float c = j.cprev ? f * j.cprev[hb] + i * g : i * g;
-            j.h[hb] = o * tanhf(c);
-            j.c[hb] = c;
-        }
+    if (tid < 64 && r0 + crow < B) {
+        const float i = act[crow * 16 + cu], f = act[crow * 16 + 4 + cu], g = act[crow * 16 + 8 + cu],
+                    o = act[crow * 16 + 12 + cu];
+        const float c = j.cprev ? f * cprev_v + i * g : i * g;
+        j.h[hb] = o * tanhf(c);
+        j.c[hb] = c;
     }
 }
 
+// One BPTT launch carries up to 2L-1 single-source jobs (16 rows x 16 hidden units x K = 4H each):
+//   kind 0 "cell":  dh = src . WT (+ ext) -> gate gradients dG^l_t      src = dG^l_{t+1}, WT = Wh_l^T,
+//                                                                        ext = dX_l[t] (or d/d(hT) for the top layer)
+//   kind 1 "xproj": dX_l[t] = src . WT                                   src = dG^{l+1}_t, WT = Wx_{l+1}^T
+// Splitting the lower layers' two contractions into two jobs one launch apart (skew 2 per layer instead of 1)
+// makes every block move the same 128 KB and spreads a launch over more CUs: the step is bound by how fast
+// a CU can pull its operands (profiles/r01: 10.3 us per launch with the fused two-source job), not by MFMA.
 struct BwdJob {
-    const float* dGup;    // [B,4H] dG^{l+1}_t or null (top layer)
-    const float* WxTup;   // [H,4H] = Wx_{l+1}^T
-    const float* dGnext;  // [B,4H] dG^l_{t+1} or null (t == T-1)
-    const float* WhT;     // [H,4H] = Wh_l^T
-    const float* dhext;   // [B,dhext_ld] external gradient (top layer, t == T-1) or null
-    const float* gates;   // [B,4H] i,f,g,o at (l,t)
-    const float* c;       // [B,H] c_t
-    const float* cprev;   // [B,H] c_{t-1} or null (t == 0)
-    const float* dcin;    // [B,H] dc_{t+1} * f_{t+1} or null (t == T-1)
-    float* dcout;         // [B,H] dc_t * f_t
-    float* dG;            // [B,4H] pre-activation gate gradients
-    int dhext_ld;
-    int pad;
+    const float* src;     // [B,4H]  or null (cell at t == T-1: no recurrent term)
+    const float* WT;      // [H,4H]
+    const float* ext;     // [B,ext_ld] added to dh (cell) or null
+    const float* gates;   // [B,4H] i,f,g,o at (l,t)            (cell)
+    const float* c;       // [B,H] c_t                          (cell)
+    const float* cprev;   // [B,H] c_{t-1} or null (t == 0)     (cell)
+    const float* dcin;    // [B,H] dc_{t+1} * f_{t+1} or null   (cell)
+    float* dcout;         // [B,H] dc_t * f_t                   (cell)
+    float* out;           // cell: dG [B,4H];  xproj: dX [B,H]
+    int ext_ld;
+    int kind;
 };
+#define ARCVAE_MAX_BWD_JOBS 16
 struct BwdArgs {
-    BwdJob job[ARCVAE_MAX_LAYERS];
+    BwdJob job[ARCVAE_MAX_BWD_JOBS];
     int B, H;
 };
 
-// 16 waves: wave w owns 4H/16 = 16*CH floats of the contraction index per source.
+// 16 waves: wave w owns 4H/16 = 16*CH floats of the contraction index.
 template <int CH>
 __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     __shared__ float red[16 * 256];
@@ -124,46 +130,43 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     const int r0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
     const int arow = min(r0 + (lane & 15), B - 1);
     const long wrow = u0 + (lane & 15);
-    const bool s1 = j.dGup != nullptr, s2 = j.dGnext != nullptr;
+    const bool cell = j.kind == 0;
+    // epilogue operands first: their cold round trip overlaps the operand loads (see the forward kernel)
+    const int erow = tid >> 4, ecol = tid & 15;
+    const int eb = min(r0 + erow, B - 1);
+    const int unit = u0 + ecol;
+    const long hb = (long)eb * H + unit;
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c_v = 0.f, cprev_v = 0.f, dcin_v = 0.f, ext_v = 0.f;
+    if (tid < 256 && cell) {
+        const float* gp = j.gates + (long)eb * G + unit;
+        gi = gp[0]; gf = gp[H]; gg = gp[2 * H]; go = gp[3 * H];
+        c_v = j.c[hb];
+        if (j.cprev) cprev_v = j.cprev[hb];
+        if (j.dcin) dcin_v = j.dcin[hb];
+        if (j.ext) ext_v = j.ext[(long)eb * j.ext_ld + unit];
+    }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (CH <= 4) {  // both sources' operands fit the 128-VGPR budget of a 1024-thread block
-        SkinnyFrag<CH> f1, f2;
-        if (s1) skinny_load<CH>(f1, j.dGup, (long)arow * G, j.WxTup, wrow * G, wave, lane);
-        if (s2) skinny_load<CH>(f2, j.dGnext, (long)arow * G, j.WhT, wrow * G, wave, lane);
-        if (s1) skinny_mfma<CH>(f1, acc0, acc1);
-        if (s2) skinny_mfma<CH>(f2, acc0, acc1);
-    } else {
+    if (j.src) {
         SkinnyFrag<CH> f;
-        if (s1) {
-            skinny_load<CH>(f, j.dGup, (long)arow * G, j.WxTup, wrow * G, wave, lane);
-            skinny_mfma<CH>(f, acc0, acc1);
-        }
-        if (s2) {
-            skinny_load<CH>(f, j.dGnext, (long)arow * G, j.WhT, wrow * G, wave, lane);
-            skinny_mfma<CH>(f, acc0, acc1);
-        }
+        skinny_load<CH>(f, j.src, (long)arow * G, j.WT, wrow * G, wave, lane);
+        skinny_mfma<CH>(f, acc0, acc1);
     }
     skinny_store_partial_n(red, acc0, acc1, wave, lane);
     __syncthreads();
-    if (tid < 256) {
-        const int row = tid >> 4, col = tid & 15;
-        const int b = r0 + row;
-        if (b < B) {
-            const int unit = u0 + col;
-            const long hb = (long)b * H + unit;
-            float dh = skinny_reduced_n<16>(red, row, col);
-            if (j.dhext) dh += j.dhext[(long)b * j.dhext_ld + unit];
-            const float* gp = j.gates + (long)b * G + unit;
-            const float i = gp[0], f = gp[H], g = gp[2 * H], o = gp[3 * H];
-            const float tc = tanhf(j.c[hb]);
+    if (tid < 256 && r0 + erow < B) {
+        const float dh = skinny_reduced_n<16>(red, erow, ecol) + ext_v;
+        if (!cell) {
+            j.out[hb] = dh;
+        } else {
+            const float i = gi, f = gf, g = gg, o = go;
+            const float tc = tanhf(c_v);
             const float d_o = dh * tc * o * (1.f - o);
-            float dc = dh * o * (1.f - tc * tc);
-            if (j.dcin) dc += j.dcin[hb];
+            const float dc = dh * o * (1.f - tc * tc) + dcin_v;
             const float d_i = dc * g * i * (1.f - i);
-            const float d_f = j.cprev ? dc * j.cprev[hb] * f * (1.f - f) : 0.f;
+            const float d_f = j.cprev ? dc * cprev_v * f * (1.f - f) : 0.f;
             const float d_g = dc * i * (1.f - g * g);
             j.dcout[hb] = dc * f;
-            float* dp = j.dG + (long)b * G + unit;
+            float* dp = j.out + (long)eb * G + unit;
             dp[0] = d_i;
             dp[H] = d_f;
             dp[2 * H] = d_g;
@@ -242,18 +245,24 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
 // BPTT for the stack.  Only h_{T-1} of the top layer receives an external gradient
 // (models/encoder.py:106).  Produces dG [L,T,B,4H] (pre-activation gate gradients); weight
 // gradients are formed from dG by arcvae_enc_lstm_wgrad.
-//   dcs  workspace [L,T,B,H];  wT workspace [(2L-1),H,4H] (transposed Wh_l, Wx_l copies, refreshed here)
+//   dcs, dxs  workspaces [L,T,B,H];  wT workspace [(2L-1),H,4H] (transposed Wh_l, Wx_l copies, refreshed
+//   when s_begin == 0).  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
+//   Schedule: cell(l,t) at launch (T-1-t) + 2(L-1-l); xproj_l(t) (dX_l[t] = dG^{l+1}_t . Wx_{l+1}) one launch earlier.
+//   After launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).
 extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
-                                        float* dcs, float* wT, int B, int T, int H, int L, hipStream_t stream) {
-    if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !wT) return ARCVAE_ERR_ARG;
+                                        float* dcs, float* dxs, float* wT, int B, int T, int H, int L,
+                                        int s_begin, int s_end, hipStream_t stream) {
+    if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
+    const int S = T + 2 * (L - 1);
+    if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
     const long wsz = (long)H * 4 * H;
     // transposed weight copies: WhT[l] at wT + l*wsz, WxT[l] (l>=1) at wT + (L + l - 1)*wsz
-    {
+    if (s_begin == 0) {
         const float* src[16];
         float* dst[16];
         int rows[16], cols[16];
@@ -266,71 +275,92 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         const int rc = arcvae_transpose_batched(src, dst, rows, cols, n, stream);
         if (rc != ARCVAE_OK) return rc;
     }
-    for (int s = 0; s < T + L - 1; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
         a.B = B; a.H = H;
         int nj = 0;
         for (int l = L - 1; l >= 0; --l) {
-            const int t = T - 1 - (s - (L - 1 - l));
-            if (t < 0 || t >= T) continue;
-            BwdJob& j = a.job[nj++];
-            const bool top = (l == L - 1), last = (t == T - 1);
-            j.dGup = top ? nullptr : dG + (l + 1) * lG + t * sG;
-            j.WxTup = top ? nullptr : wT + (L + l) * wsz;  // WxT[l+1]
-            j.dGnext = last ? nullptr : dG + l * lG + (t + 1) * sG;
-            j.WhT = wT + l * wsz;
-            j.dhext = (top && last) ? dh_top : nullptr;
-            j.gates = gseq + l * lG + t * sG;
-            j.c = cseq + l * lH + t * sH;
-            j.cprev = t > 0 ? cseq + l * lH + (t - 1) * sH : nullptr;
-            j.dcin = last ? nullptr : dcs + l * lH + (t + 1) * sH;
-            j.dcout = dcs + l * lH + t * sH;
-            j.dG = dG + l * lG + t * sG;
-            j.dhext_ld = ld_dh_top;
-            j.pad = 0;
+            const int skew = 2 * (L - 1 - l);
+            const int t = T - 1 - (s - skew);          // cell(l, t)
+            if (t >= 0 && t < T) {
+                BwdJob& j = a.job[nj++];
+                const bool top = (l == L - 1), last = (t == T - 1);
+                j.kind = 0;
+                j.src = last ? nullptr : dG + l * lG + (t + 1) * sG;
+                j.WT = wT + l * wsz;
+                if (top) { j.ext = last ? dh_top : nullptr; j.ext_ld = ld_dh_top; }
+                else { j.ext = dxs + l * lH + t * sH; j.ext_ld = H; }
+                j.gates = gseq + l * lG + t * sG;
+                j.c = cseq + l * lH + t * sH;
+                j.cprev = t > 0 ? cseq + l * lH + (t - 1) * sH : nullptr;
+                j.dcin = last ? nullptr : dcs + l * lH + (t + 1) * sH;
+                j.dcout = dcs + l * lH + t * sH;
+                j.out = dG + l * lG + t * sG;
+            }
+            const int tx = T - 1 - (s + 1 - skew);     // xproj_l(tx): feeds cell(l, tx) at the next launch
+            if (l < L - 1 && tx >= 0 && tx < T) {
+                BwdJob& j = a.job[nj++];
+                j.kind = 1;
+                j.src = dG + (l + 1) * lG + tx * sG;
+                j.WT = wT + (L + l) * wsz;             // WxT[l+1]
+                j.ext = nullptr; j.ext_ld = H;
+                j.gates = nullptr; j.c = nullptr; j.cprev = nullptr; j.dcin = nullptr; j.dcout = nullptr;
+                j.out = dxs + l * lH + tx * sH;
+            }
         }
-        for (int k = nj; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
+        if (nj == 0) continue;
+        for (int k = nj; k < ARCVAE_MAX_BWD_JOBS; ++k) a.job[k] = a.job[0];
         dim3 grid(H / 16, ceil_div(B, 16), nj);
         DISPATCH_CH(H, launch_bwd, a, grid, stream)
     }
     return arcvae_launch_status();
 }
 
-// Weight gradients of the stack from dG (all "+=" into the caller's gradient buffers):
-//   l >= 1: dWx_l += dG_l^T . hseq_{l-1};   all l: dWh_l += dG_l[1:]^T . hseq_l[:-1];  dbias_l += colsum(dG_l)
-//   l == 0: dTable0[v] = sum_{(t,b): x=v} dG_0[t,b]  ->  dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;
-//           dbias_0 += colsum(dTable0)
-//   dtable_ws: workspace [V,4H]
+// Weight gradients of the stack from dG over the time range [t_lo, t_hi) (all "+=" into the caller's
+// gradient buffers), so that chunks can run on another stream while the BPTT sweep is still going:
+//   l >= 1: dWx_l += dG_l[t]^T . hseq_{l-1}[t];  all l: dWh_l += dG_l[t]^T . hseq_l[t-1] (t >= 1);  dbias_l += colsum
+//   l == 0: dTable0[v] += sum_{(t,b): x=v} dG_0[t,b]   (dtable_ws [V,4H], zeroed when `first` != 0)
+//   when `last` != 0 (all ranges done): dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;  dbias_0 += colsum(dTable0)
 extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0,
                                      const float* hseq, const float* dG, float* dtable_ws, float* dEmb,
                                      float* const* dWx, float* const* dWh, float* const* dbias, int B, int T,
-                                     int V, int E, int H, int L, hipStream_t stream) {
+                                     int V, int E, int H, int L, int t_lo, int t_hi, int first, int last,
+                                     hipStream_t stream) {
     if (!x_tb || !emb || !Wx0 || !hseq || !dG || !dtable_ws || !dEmb || !dWx || !dWh || !dbias)
         return ARCVAE_ERR_ARG;
+    if (t_lo < 0 || t_hi > T || t_lo > t_hi) return ARCVAE_ERR_ARG;
     const int G = 4 * H, TB = T * B;
     const long lH = (long)TB * H, lG = (long)TB * G;
+    const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK;
     int rc;
-    for (int l = 0; l < L; ++l) {
-        const float* dGl = dG + l * lG;
-        if (T > 1) {
-            rc = arcvae_gemm_f32(1, 0, G, H, (T - 1) * B, dGl + (long)B * G, G, hseq + l * lH, H, dWh[l], H,
-                                 nullptr, ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK, stream);
-            if (rc) return rc;
+    if (first && arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+    if (t_hi > t_lo) {
+        const int nt = t_hi - t_lo;
+        for (int l = 0; l < L; ++l) {
+            const float* dGl = dG + l * lG;
+            const int t1 = t_lo > 1 ? t_lo : 1;  // dWh pairs dG[t] with h[t-1]
+            if (t_hi > t1) {
+                rc = arcvae_gemm_f32(1, 0, G, H, (t_hi - t1) * B, dGl + (long)t1 * B * G, G,
+                                     hseq + l * lH + (long)(t1 - 1) * B * H, H, dWh[l], H, nullptr, SK, stream);
+                if (rc) return rc;
+            }
+            if (l > 0) {
+                rc = arcvae_gemm_f32(1, 0, G, H, nt * B, dGl + (long)t_lo * B * G, G,
+                                     hseq + (l - 1) * lH + (long)t_lo * B * H, H, dWx[l], H, nullptr, SK, stream);
+                if (rc) return rc;
+                rc = arcvae_colsum_accum(dGl + (long)t_lo * B * G, nt * B, G, G, dbias[l], 1.0f, stream);
+                if (rc) return rc;
+            }
         }
-        if (l > 0) {
-            rc = arcvae_gemm_f32(1, 0, G, H, TB, dGl, G, hseq + (l - 1) * lH, H, dWx[l], H, nullptr,
-                                 ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK, stream);
-            if (rc) return rc;
-            rc = arcvae_colsum_accum(dGl, TB, G, G, dbias[l], 1.0f, stream);
-            if (rc) return rc;
-        }
+        rc = arcvae_segsum_rows_accum(dG + (long)t_lo * B * G, x_tb + (long)t_lo * B, nt * B, V, G, dtable_ws, stream);
+        if (rc) return rc;
     }
-    if (hipMemsetAsync(dtable_ws, 0, (size_t)V * G * sizeof(float), stream) != hipSuccess) return ARCVAE_ERR_LAUNCH;
-    rc = arcvae_segsum_rows_accum(dG, x_tb, TB, V, G, dtable_ws, stream);
-    if (rc) return rc;
-    rc = arcvae_gemm_f32(0, 0, V, E, G, dtable_ws, G, Wx0, E, dEmb, E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
-    if (rc) return rc;
-    rc = arcvae_gemm_f32(1, 0, G, E, V, dtable_ws, G, emb, E, dWx[0], E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
-    if (rc) return rc;
-    return arcvae_colsum_accum(dtable_ws, V, G, G, dbias[0], 1.0f, stream);
+    if (last) {
+        rc = arcvae_gemm_f32(0, 0, V, E, G, dtable_ws, G, Wx0, E, dEmb, E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
+        if (rc) return rc;
+        rc = arcvae_gemm_f32(1, 0, G, E, V, dtable_ws, G, emb, E, dWx[0], E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
+        if (rc) return rc;
+        return arcvae_colsum_accum(dtable_ws, V, G, G, dbias[0], 1.0f, stream);
+    }
+    return arcvae_launch_status();
 }

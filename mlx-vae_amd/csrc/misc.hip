@@ -121,6 +121,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+__global__ void zero2d_kernel(float* x, int rows, int cols, int ld) {
+    const long n = (long)rows * cols;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[(i / cols) * ld + (i % cols)] = 0.f;
+}
+
 __global__ void scale_kernel(float* x, long n, float s) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= s;
@@ -184,6 +190,16 @@ extern "C" int arcvae_adam_update(float* params, const float* grads, float* m, f
     const int blocks = (int)min((long)2048, (work + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, m, v, n4, n, (float)lr,
                        (float)beta1, (float)beta2, omb1, omb2, (float)eps);
+    return arcvae_launch_status();
+}
+
+// x[r*ld + c] = 0 for r < rows, c < cols.  A kernel rather than hipMemsetAsync: memset NODES of a captured
+// single-stream segment replayed garbage on ROCm 7.2 (tools/debug_replay.py), kernels replay faithfully.
+extern "C" int arcvae_zero(float* x, int rows, int cols, int ld, hipStream_t stream) {
+    if (!x || rows <= 0 || cols <= 0 || ld < cols) return ARCVAE_ERR_ARG;
+    const long n = (long)rows * cols;
+    const int blocks = (int)min((long)1024, (n + 255) / 256);
+    hipLaunchKernelGGL(zero2d_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld);
     return arcvae_launch_status();
 }
 

@@ -22,6 +22,8 @@ int arcvae_transpose_batched(const float* const* src, float* const* dst, const i
 // out[seg[r], :] += X[r, :]   (out is [nseg, cols], pre-initialised by the caller)
 int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int rows, int nseg, int cols,
                              float* out, hipStream_t stream);
+// x[r*ld + c] = 0
+int arcvae_zero(float* x, int rows, int cols, int ld, hipStream_t stream);
 // dst[t*B + b] = src[b*T + t]
 int arcvae_transpose_tokens(const int32_t* src, int32_t* dst, int B, int T, hipStream_t stream);
 }

@@ -107,3 +107,23 @@ def test_logits_do_not_depend_on_z_or_eps():
     torch.cuda.synchronize()
     assert float(b["total_loss"]) == la
     assert not np.allclose(b["z"].cpu().numpy(), za)
+
+
+def test_dp_driver_single_rank_rccl():
+    """Rehearsal of the N-rank path on one GPU: process group (backend nccl = RCCL), stats and gradient
+    all-reduces forced on at world size 1, captured segments; the loss must match the plain engine's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    for extra in (["--force-dp"], []):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3",
+                            "--cpu-steps", "0", "--no-roofline"] + extra, capture_output=True, text=True, env=env,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    a, b = outs
+    assert a["n_gpus"] == 1 and abs(a["elbo"]["total"] - b["elbo"]["total"]) < 1e-4 * max(1.0, abs(b["elbo"]["total"]))
