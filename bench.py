@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mode", choices=["auto", "graph", "eager", "segments"], default="auto",
                     help="launch mode: one multi-stream hipGraph, eager launches, or per-stream graph segments")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=6, help="oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel driver (process group + collectives) even at world size 1")
@@ -243,31 +243,36 @@ def main():
 def roofline_probe(eng, ws, torch):
     """Live HIP-event timing of the dominant kernel on the stream it is launched on.
 
-    Dominant kernel (by summed device time, profiles/): lstm_bwd_step_kernel, the BPTT wavefront
-    step.  Algorithmic FLOPs per launch (steady state, both layers in flight at the default shape):
-    layer 1: dG_1[t+1] . Wh_1 (2*B*4H*H); layer 0: dG_1[t] . Wx_1 + dG_0[t+1] . Wh_0 (2 * 2*B*4H*H).
-    It is timed as the whole arcvae_enc_lstm_backward call (T+L-1 dependent launches + one weight
-    transpose) between two events, divided by the launch count, so the figure includes the
-    launch-boundary gaps of the dependent chain -- which is what bounds this path.
+    Dominant kernel (largest share of device time, profiles/): lstm_bwd_step_kernel, one launch of the BPTT
+    wavefront.  A steady-state launch carries 2L-1 single-source jobs (L cell steps dG_{t+1} . Wh^T and L-1
+    input-gradient projections dG^{l+1}_t . Wx^T), each a [B,4H] x [4H,H] contraction = 2*B*4H*H FLOP.
+    Timed as the whole arcvae_enc_lstm_backward call (T+2(L-1) dependent launches, replayed as one linear
+    hipGraph) between two events on the launching stream, divided by the launch count: launches of a
+    dependent chain are back to back, so this is the per-launch figure rocprofv3's kernel trace reports
+    (its start stamp of launch n+1 is the end stamp of launch n).
+    `traffic`: fabric-side bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md
+    HBM section), taken from profiles/ (separate --pmc passes), not measured here.
     """
     from arcvae_hip import engine as E
     d = eng.d
     B, Tn = ws.B, ws.T
     wx, _k1 = E._layer_ptrs(eng.enc, d.L, "Wx", skip0=True)
     wh, _k2 = E._layer_ptrs(eng.enc, d.L, "Wh")
-    s = torch.cuda.current_stream()
+    launches = Tn + 2 * (d.L - 1)
     reps = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def sweep():
         E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * d.H,
-               E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, Tn, d.H, d.L, 0, Tn + 2 * (d.L - 1), E.stream_ptr())
+               E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, Tn, d.H, d.L, 0, launches,
+               E.stream_ptr())
 
-    g = torch.cuda.CUDAGraph()
     sweep()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         sweep()
+    s = torch.cuda.current_stream()
     g.replay()
     torch.cuda.synchronize()
     e0.record(s)
@@ -275,16 +280,22 @@ def roofline_probe(eng, ws, torch):
         g.replay()
     e1.record(s)
     torch.cuda.synchronize()
-    launches = Tn + 2 * (d.L - 1)
     us = 1e3 * e0.elapsed_time(e1) / reps / launches
-    jobs = d.L * Tn
-    flops_total = 2.0 * B * 4 * d.H * d.H * (jobs - d.L + (d.L - 1) * Tn)  # Wh terms (t<T-1) + Wx_up terms
-    flops_per_launch = flops_total / launches
-    ach = flops_per_launch / (us * 1e-6) / 1e12
+    flops_total = 2.0 * B * 4 * d.H * d.H * (d.L * (Tn - 1) + (d.L - 1) * Tn)
+    ach = flops_total / launches / (us * 1e-6) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("lstm_bwd_step_kernel", {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "kernel": "lstm_bwd_step_kernel", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
             "us_per_launch": us, "launches_per_sweep": launches,
-            "note": "f32-input MFMA peak; per-launch time includes the dependent-launch gap (chain-latency bound)"}
+            "flop_per_launch": flops_total / launches,
+            "note": "f32-input MFMA peak (exact-f32 path); the launch is bound by the dependent-chain seam "
+                    "(1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6"}
 
 
 if __name__ == "__main__":
