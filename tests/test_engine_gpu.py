@@ -127,3 +127,36 @@ def test_dp_driver_single_rank_rccl():
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     a, b = outs
     assert a["n_gpus"] == 1 and abs(a["elbo"]["total"] - b["elbo"]["total"]) < 1e-4 * max(1.0, abs(b["elbo"]["total"]))
+
+
+@pytest.mark.parametrize("H,L,B,T,C", [(512, 4, 24, 10, 1), (128, 1, 33, 9, 2), (192, 2, 16, 8, 1), (320, 3, 7, 6, 4)])
+def test_step_other_hidden_sizes_and_depths(H, L, B, T, C):
+    """BASELINE.json configs[2] family (H512, 4 layers) and the other CH = H/64 template instances;
+    single layer, ragged batches, several conditions."""
+    cfg = O.Config(vocab_size=60, embedding_dim=64, hidden_dim=H, latent_dim=32, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):  # second call replays the captured segments
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+    assert not bad, bad
+
+
+def test_unsupported_shapes_are_argument_errors():
+    from arcvae_hip.engine import ModelDims
+    for kw in (dict(H=100), dict(H=576), dict(V=200), dict(C=9), dict(L=9)):
+        d = dict(V=80, E=16, H=64, Z=8, C=1, L=2)
+        d.update(kw)
+        with pytest.raises(ValueError):
+            ModelDims(**d).validate()
