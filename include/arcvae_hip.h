@@ -35,7 +35,9 @@ extern "C" {
 #define ARCVAE_GEMM_ACCUMULATE 1 /* C += ...                                   */
 #define ARCVAE_GEMM_TANH 2       /* C = tanh(...)                              */
 #define ARCVAE_GEMM_SPLITK 4     /* allow split-K with f32 atomics             */
-#define ARCVAE_GEMM_NO_SKINNY 8  /* force the tile kernel                      */
+#define ARCVAE_GEMM_NO_SKINNY 8
+#define ARCVAE_GEMM_TILE64 16   /* force 64x64 tiles (tuning / tests) */
+#define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */  /* force the tile kernel                      */
 
 typedef void* arcvae_stream_t; /* hipStream_t */
 
@@ -95,6 +97,9 @@ int arcvae_stats_set_recon(const float* rowloss, int B, float* stats, int Z, arc
 int arcvae_latent_loss(const float* stats, const float* hyper, const float* mu, const float* logvar,
                        float* scalars, float* dmu_raw, float* dlv_raw, int B, int Z, int T, float free_bits,
                        arcvae_stream_t stream);
+/* recon = stats[2Z+3]/(B_global*T) and total, once the decoder's CE row sums are in stats (latent_loss may run
+ * before that: the encoder's backward does not depend on the reconstruction term, Q2). */
+int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, arcvae_stream_t stream);
 int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* Wlh, const float* Wlv,
                               const float* comb, const float* lh, const float* dmu_raw, const float* dlv_raw,
                               float* dlh, float* dcomb, float* dWc, float* dbc, float* dWmu, float* dbmu,

@@ -33,14 +33,16 @@ import torch.distributed as dist
 
 
 class StepOps(Protocol):
-    stats: torch.Tensor
+    stats: torch.Tensor        # per-rank partial latent sums (2Z+3 floats), all-reduced before the backward
+    recon_stat: torch.Tensor   # per-rank CE sum (1 float), all-reduced off the critical path
 
     def forward_local(self) -> None: ...      # fills self.stats with this rank's partial sums
     def backward_local(self) -> None: ...     # self.stats now holds GLOBAL sums; fills all gradients
     def early_buckets(self) -> List[torch.Tensor]: ...  # gradients ready before backward_local completes
     def late_buckets(self) -> List[torch.Tensor]: ...   # gradients ready after backward_local
-    def early_context(self) -> ContextManager: ...      # stream context the early reduce is issued from
-    def apply_update(self) -> None: ...
+    def early_context(self) -> ContextManager: ...      # stream context the early reduces are issued from
+    def recon_local(self) -> None: ...        # fills self.recon_stat (inside early_context)
+    def apply_update(self) -> None: ...       # self.recon_stat now holds the GLOBAL CE sum
 
 
 class DataParallelStep:
@@ -59,10 +61,12 @@ class DataParallelStep:
     def step(self) -> None:
         ops = self.ops
         ops.forward_local()
-        self._all_reduce(ops.stats)
+        self._all_reduce(ops.stats)                     # forward seam (critical path, 2Z+3 floats)
         ops.backward_local()
-        with ops.early_context():
-            works = [self._all_reduce(g, async_op=True) for g in ops.early_buckets()]
+        with ops.early_context():                       # decoder-side results: overlap the encoder BPTT
+            ops.recon_local()
+            works = [self._all_reduce(ops.recon_stat, async_op=True)]
+            works += [self._all_reduce(g, async_op=True) for g in ops.early_buckets()]
         for g in ops.late_buckets():
             self._all_reduce(g)
         for w in works:
@@ -72,36 +76,43 @@ class DataParallelStep:
 
 
 class EngineOps:
-    """StepOps over the HIP StepEngine (engine.py): the engine's three phases with the collectives between.
+    """StepOps over the HIP StepEngine (engine.py): the engine's phases with the collectives between.
 
+    main stream : [enc_fwd] -> (all-reduce stats) -> [loss + dcomb + sweep chunks...] -> (all-reduce enc.grad)
+                  -> [finalize + adam]
     side stream : [dec_fwd] -> ev_chain -> [dec_bwd] -> ev_dec_bwd
-    main stream : [enc_fwd] -> wait ev_chain -> [recon] -> (all-reduce stats)
-                  -> [loss][heads1][sweep chunks...] -> (all-reduce enc.grad) -> [adam]
-    aux stream  : [heads2][wgrad chunks...] behind the sweep
-    comm stream : wait ev_dec_bwd -> (all-reduce dec.grad), overlapping the encoder BPTT
+    aux stream  : [heads' and LSTM weight gradients, chunk by chunk behind the sweep]
+    comm stream : wait ev_chain -> recon sum -> (all-reduce) ; wait ev_dec_bwd -> (all-reduce dec.grad)
     """
 
     def __init__(self, engine, ws, lr: float, global_rows: int, use_graph: bool = True):
         self.eng, self.ws, self.lr = engine, ws, float(lr)
         self.global_rows = int(global_rows)
-        self.stats = ws.stats
+        Z = engine.d.Z
+        self.stats = ws.stats[:2 * Z + 3]
+        self.recon_stat = ws.stats[2 * Z + 3:2 * Z + 4]
         self.run = engine.runner(ws, lr, global_rows, capture=use_graph)
         self.comm = torch.cuda.Stream(device=engine.device)
 
     def forward_local(self) -> None:
-        self.eng.enqueue_forward(self.ws, self.global_rows, self.run)
+        self.eng.enqueue_encoder_forward(self.ws, self.run)
+        self.eng.enqueue_decoder(self.ws, self.global_rows, self.run)
 
     def backward_local(self) -> None:
         self.eng.enqueue_backward(self.ws, self.run)
 
     @contextlib.contextmanager
     def early_context(self):
-        # issue the decoder-bucket reduce from the comm stream so it does not queue behind BPTT
-        self.comm.wait_event(self.eng.ev_dec_bwd)
+        # decoder-side collectives are issued from the comm stream so they do not queue behind BPTT
+        self.comm.wait_event(self.eng.ev_enc_fwd)  # the encoder forward zero-fills `stats` before the CE slot is set
         with torch.cuda.stream(self.comm):
             yield
 
+    def recon_local(self) -> None:
+        self.eng.enqueue_recon(self.ws, self.run)            # waits ev_chain on the comm stream
+
     def early_buckets(self) -> List[torch.Tensor]:
+        torch.cuda.current_stream().wait_event(self.eng.ev_dec_bwd)
         return [self.eng.dec.grad]
 
     def late_buckets(self) -> List[torch.Tensor]:
@@ -109,4 +120,4 @@ class EngineOps:
 
     def apply_update(self) -> None:
         torch.cuda.current_stream().wait_stream(self.comm)
-        self.eng.enqueue_update(self.lr, self.run)
+        self.eng.enqueue_finish(self.ws, self.lr, True, self.run)

@@ -222,63 +222,95 @@ class SegmentRunner:
                 g.replay()
 
 
-def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
-                     nchunks: int = 4, run=_inline) -> None:
-    """Backward of heads + LSTM stack.  Critical path on the current stream: dcomb chain -> BPTT wavefront.
-    With `aux`, everything that only produces parameter gradients (heads' weight grads, then the LSTM
-    weight-gradient GEMMs chunk by chunk as the sweep releases time ranges) runs on that stream, overlapped
-    with the sweep; the current stream joins `aux` before returning.  `run(key, fn, stream)` executes one
-    single-stream segment (inline, or through a SegmentRunner)."""
-    B, T, L = ws.B, ws.T, d.L
-    main = torch.cuda.current_stream()
+class EncoderBackwardPlan:
+    """The pieces of the encoder backward as closures over (enc, ws), plus the chunk schedule.
 
-    def heads(phase):
+    Critical chain (main stream): heads(1) [dcomb] -> sweep chunks.  Off the chain (aux stream): heads(2)
+    [the heads' parameter gradients] and wgrad chunks, each released by an event after the sweep chunk that
+    completes its time range.  Chunks shrink geometrically so the part of the weight-gradient work that
+    cannot overlap the sweep (the last chunk) is small."""
+
+    FRACTIONS = (0.3, 0.6, 0.85, 1.0)
+
+    def __init__(self, enc: ParamStore, ws: Workspace, d: ModelDims):
+        self.enc, self.ws, self.d = enc, ws, d
+        L, T = d.L, ws.T
+        self.S = T + 2 * (L - 1)  # launches of the BPTT wavefront (csrc/lstm.hip)
+        self._wx = _layer_ptrs(enc, L, "Wx", skip0=True)
+        self._wh = _layer_ptrs(enc, L, "Wh")
+        self._dwx = _layer_ptrs(enc, L, "Wx", grad=True)
+        self._dwh = _layer_ptrs(enc, L, "Wh", grad=True)
+        self._dbs = _layer_ptrs(enc, L, "bias", grad=True)
+        bounds = sorted({0, self.S} | {min(self.S, max(1, round(f * self.S))) for f in self.FRACTIONS})
+        self.chunks = []  # (s0, s1, t_lo, t_hi, first, last)
+        t_hi = T
+        for s0, s1 in zip(bounds[:-1], bounds[1:]):
+            # after launches [0, s1) every layer has finished all t >= T - s1 + 2(L-1)
+            t_lo = 0 if s1 >= self.S else min(T, max(0, T - s1 + 2 * (L - 1)))
+            self.chunks.append((s0, s1, t_lo, t_hi, t_hi == T, s1 >= self.S))
+            t_hi = t_lo
+
+    def heads(self, phase: int) -> None:
+        enc, ws, d = self.enc, self.ws, self.d
         call("arcvae_enc_heads_backward", ptr(ws.cond), ptr(enc.p("fc_mu.weight")),
              ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar.weight")), ptr(ws.comb), ptr(ws.lh),
              ptr(ws.dmu_raw), ptr(ws.dlv_raw), ptr(ws.dlh), ptr(ws.dcomb), ptr(enc.g("condition_fc.weight")),
              ptr(enc.g("condition_fc.bias")), ptr(enc.g("fc_mu.weight")), ptr(enc.g("fc_mu.bias")),
              ptr(enc.g("fc_logvar_hidden.weight")), ptr(enc.g("fc_logvar_hidden.bias")),
-             ptr(enc.g("fc_logvar.weight")), ptr(enc.g("fc_logvar.bias")), B, d.H, d.Z, d.C, phase, stream_ptr())
+             ptr(enc.g("fc_logvar.weight")), ptr(enc.g("fc_logvar.bias")), ws.B, d.H, d.Z, d.C, phase, stream_ptr())
 
-    wx, _k1 = _layer_ptrs(enc, L, "Wx", skip0=True)
-    wh, _k2 = _layer_ptrs(enc, L, "Wh")
-    dwx, _k3 = _layer_ptrs(enc, L, "Wx", grad=True)
-    dwh, _k4 = _layer_ptrs(enc, L, "Wh", grad=True)
-    dbs, _k5 = _layer_ptrs(enc, L, "bias", grad=True)
+    def sweep(self, s0: int, s1: int) -> None:  # d/d(hT) = dcomb[:, :H] (row stride 2H)
+        ws, d = self.ws, self.d
+        call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
+             2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1, stream_ptr())
 
-    def sweep(s0, s1):  # d/d(hT) = dcomb[:, :H] (row stride 2H)
-        call("arcvae_enc_lstm_backward", wx, wh, ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG),
-             ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), B, T, d.H, L, s0, s1, stream_ptr())
-
-    def wgrad(t_lo, t_hi, first, last):
+    def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool) -> None:
+        enc, ws, d = self.enc, self.ws, self.d
         call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
-             ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(enc.g("embedding.weight")), dwx, dwh, dbs, B, T, d.V,
-             d.E, d.H, L, t_lo, t_hi, int(first), int(last), stream_ptr())
+             ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(enc.g("embedding.weight")), self._dwx[0], self._dwh[0],
+             self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), stream_ptr())
 
-    S = T + 2 * (L - 1)  # launches of the BPTT wavefront (csrc/lstm.hip)
+
+def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
+                     run=_inline, prologue=None, after_first=None) -> None:
+    """Backward of heads + LSTM stack on (current stream, aux).  `prologue` (optional) is enqueued at the head
+    of the first main-stream segment (used to fuse encoder forward + loss into it); `after_first` (optional) is
+    called on the host right after that first segment has been enqueued (the decoder is enqueued there: early
+    enough to finish beside the sweep, but never ahead of the critical chain).  The current stream joins `aux`
+    before returning."""
+    plan = EncoderBackwardPlan(enc, ws, d)
+    main = torch.cuda.current_stream()
     if aux is None:
-        run("enc_bwd_all", lambda: (heads(0), sweep(0, S), wgrad(0, T, True, True)), main)
+        def everything():
+            if prologue:
+                prologue()
+            plan.heads(0)
+            plan.sweep(0, plan.S)
+            plan.wgrad(0, ws.T, True, True)
+        run("enc_all", everything, main)
+        if after_first:
+            after_first()
         return
-    run("heads1", lambda: heads(1), main)
-    ev = torch.cuda.Event()
-    ev.record(main)
-    aux.wait_event(ev)
-    run("heads2", lambda: heads(2), aux)
-    nchunks = max(1, min(nchunks, S))
-    bounds = [round(i * S / nchunks) for i in range(nchunks + 1)]
-    t_hi = T
-    for c in range(nchunks):
-        s0, s1 = bounds[c], bounds[c + 1]
-        if s1 <= s0:
-            continue
-        run(f"sweep{c}", lambda s0=s0, s1=s1: sweep(s0, s1), main)
-        # after launches [0, s1) every layer has finished all t >= T - s1 + 2(L-1)
-        t_lo = 0 if s1 >= S else min(T, max(0, T - s1 + 2 * (L - 1)))
-        evc = torch.cuda.Event()
-        evc.record(main)
-        aux.wait_event(evc)
-        run(f"wgrad{c}", lambda a=t_lo, b=t_hi, f=(t_hi == T), l=(s1 >= S): wgrad(a, b, f, l), aux)
-        t_hi = t_lo
+    for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
+        def main_seg(c=c, s0=s0, s1=s1):
+            if c == 0:
+                if prologue:
+                    prologue()
+                plan.heads(1)
+            plan.sweep(s0, s1)
+
+        def aux_seg(c=c, t_lo=t_lo, t_hi=t_hi, first=first, last=last):
+            if c == 0:
+                plan.heads(2)
+            plan.wgrad(t_lo, t_hi, first, last)
+
+        run(f"main{c}", main_seg, main)
+        if c == 0 and after_first:
+            after_first()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        aux.wait_event(ev)
+        run(f"aux{c}", aux_seg, aux)
     main.wait_stream(aux)
 
 
@@ -312,6 +344,7 @@ class StepEngine:
         self.mode = "segments"
         self.ev_chain = torch.cuda.Event()
         self.ev_dec_bwd = torch.cuda.Event()
+        self.ev_enc_fwd = torch.cuda.Event()
 
     # `use_graph` is the older boolean switch: True -> captured segments, False -> eager launches
     @property
@@ -359,19 +392,14 @@ class StepEngine:
             self._runners[key] = SegmentRunner(capture)
         return self._runners[key]
 
-    # ---- the three phases of a step (data-parallel collectives go between them, dp.py) ------------------
-    def enqueue_forward(self, ws: Workspace, global_rows: int, run=_inline, backward: bool = True) -> None:
-        """encoder forward on main, dense decoder (+ its backward) on side; on return main holds this
-        process's partial `stats` (complete once ev_chain has been waited for)."""
-        main = torch.cuda.current_stream()
-        fb = float(self.hyper_host["free_bits"])
+    # ---- the phases of a step (data-parallel collectives go between them, dp.py) ------------------------
+    def enqueue_decoder(self, ws: Workspace, global_rows: int, run=_inline, backward: bool = True,
+                        wait_current: bool = True) -> None:
+        """Dense decoder on the side stream: forward + TF walk + CE row sums (ev_chain), then its whole backward
+        (ev_dec_bwd).  Independent of the encoder (Q2); it only has to follow the input copies."""
         d = self.d
-        self.side.wait_stream(main)
-
-        def enc_fwd():
-            if backward:
-                self.enc.grad.zero_()
-            encoder_forward(self.enc, ws, d, fb)
+        if wait_current:
+            self.side.wait_stream(torch.cuda.current_stream())
 
         def dec_fwd():
             if backward:
@@ -379,35 +407,66 @@ class StepEngine:
             decoder_forward_dense(self.dec, ws, d)
             decoder_chain(ws, d)
 
-        run("enc_fwd", enc_fwd, main)  # the critical chain is enqueued first
         run("dec_fwd", dec_fwd, self.side)
         self.ev_chain.record(self.side)
-        if backward:  # does not depend on the stats seam: keep the side stream busy
+        if backward:
             run("dec_bwd", lambda: decoder_backward(self.dec, ws, d, 1.0 / (global_rows * ws.T)), self.side)
             self.ev_dec_bwd.record(self.side)
-        main.wait_event(self.ev_chain)
-        run("recon", lambda: call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), d.Z, stream_ptr()),
-            main)
 
-    def enqueue_backward(self, ws: Workspace, run=_inline) -> None:
-        """`stats` now holds GLOBAL sums: loss scalars, latent gradients, encoder backward."""
+    def _enc_fwd(self, ws: Workspace, backward: bool) -> None:
+        if backward:
+            self.enc.grad.zero_()
+        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]))
+
+    def enqueue_encoder_forward(self, ws: Workspace, run=_inline, backward: bool = True) -> None:
+        """Encoder forward on the current stream; leaves this process's partial latent `stats` (the CE slot
+        stats[2Z+3] is filled later by enqueue_finish)."""
+        run("enc_fwd", lambda: self._enc_fwd(ws, backward), torch.cuda.current_stream())
+        self.ev_enc_fwd.record(torch.cuda.current_stream())
+
+    def enqueue_backward(self, ws: Workspace, run=_inline, fuse_forward: bool = False, after_first=None) -> None:
+        """`stats[:2Z+3]` holds GLOBAL sums (or, with fuse_forward, will: single process): latent loss scalars
+        and gradients, then the encoder backward.  Does NOT wait for the decoder."""
         fb = float(self.hyper_host["free_bits"])
-        main = torch.cuda.current_stream()
-        run("loss", lambda: latent_loss(ws, self.d, fb, True), main)
-        encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run)
 
-    def enqueue_update(self, lr: float, run=_inline) -> None:
+        def prologue():
+            if fuse_forward:
+                self._enc_fwd(ws, True)
+            latent_loss(ws, self.d, fb, True)
+
+        encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue, after_first=after_first)
+
+    def enqueue_recon(self, ws: Workspace, run=_inline) -> None:
+        """stats[2Z+3] = sum of this process's CE row sums (after the decoder's TF walk)."""
+        main = torch.cuda.current_stream()
+        main.wait_event(self.ev_chain)
+        run("recon", lambda: call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z,
+                                  stream_ptr()), main)
+
+    def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline) -> None:
+        """recon/total scalars from the (global) CE sum, join the side stream, both Adam updates."""
         main = torch.cuda.current_stream()
         main.wait_stream(self.side)
-        run("adam", lambda: (adam_update(self.dec, lr), adam_update(self.enc, lr)), main)
+
+        def fin():
+            call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
+            if update:
+                adam_update(self.dec, lr)
+                adam_update(self.enc, lr)
+
+        run("finish" if update else "finish_noupdate", fin, main)
 
     def _enqueue_step(self, ws: Workspace, lr: float, global_rows: int, update: bool, run=_inline) -> None:
-        self.enqueue_forward(ws, global_rows, run)
+        """Single-process step.  Host enqueue order = GPU priority: encoder forward first (the critical chain),
+        then the decoder (it overlaps the forward sweep, whose launches leave CUs idle at every seam), then the
+        fused loss + dcomb + BPTT segments with the weight-gradient chunks on aux; the decoder is only joined at
+        the very end (nothing on the encoder's backward path needs the reconstruction term)."""
+        self.side.wait_stream(torch.cuda.current_stream())   # the decoder only has to follow the input copies
+        self.enqueue_encoder_forward(ws, run)
+        self.enqueue_decoder(ws, global_rows, run, wait_current=False)
         self.enqueue_backward(ws, run)
-        if update:
-            self.enqueue_update(lr, run)
-        else:
-            torch.cuda.current_stream().wait_stream(self.side)
+        self.enqueue_recon(ws, run)
+        self.enqueue_finish(ws, lr, update, run)
 
     # ---- public API --------------------------------------------------------------------------------
     def forward_loss(self, x, cond, eps, coins, **hyper) -> Dict[str, torch.Tensor]:
@@ -416,8 +475,12 @@ class StepEngine:
         ws = self.workspace(B, T, train=False)
         self.set_hyper(ws, **hyper)
         self.load_inputs(ws, x, cond, eps, coins)
-        self.enqueue_forward(ws, B, backward=False)
+        self.enqueue_decoder(ws, B, backward=False)
+        self.enqueue_encoder_forward(ws, backward=False)
         latent_loss(ws, self.d, float(self.hyper_host["free_bits"]), False)
+        self.enqueue_recon(ws)
+        call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
+        torch.cuda.current_stream().wait_stream(self.side)
         return self._results(ws)
 
     def train_step(self, x, cond, eps, coins, lr: float, update: bool = True, **hyper) -> Dict[str, torch.Tensor]:

@@ -265,7 +265,14 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     const bool va4 = aligned16(A) && (lda % 4) == 0 && ((ak ? K : M) % 4) == 0;
     const bool vb4 = aligned16(B) && (ldb % 4) == 0 && ((bk ? K : N) % 4) == 0;
 
-    const bool big = (M >= 256 && N >= 128) || (M >= 128 && N >= 256);
+    // Tile choice (tools/bench_gemm.py on MI355X): the 64x64 tile (one 32x32 MFMA tile per wave, 4+ blocks per
+    // CU hiding each other's barrier bubbles) beats the 128x128 tile on every shape of the training step --
+    // 73 vs 50 TFLOP/s on the [5120,256]x[256,1024] projection, 44 vs 23 on [5120,1024]x[1024,256] -- so the
+    // big tile is only chosen when even it oversubscribes the chip several times.
+    const int blocks128 = ceil_div(M, 128) * ceil_div(N, 128);
+    bool big = M >= 128 && N >= 128 && blocks128 >= 2048;
+    if (flags & ARCVAE_GEMM_TILE128) big = true;
+    if (flags & ARCVAE_GEMM_TILE64) big = false;
     const int bm = big ? 128 : 64, bn = big ? 128 : 64;
     dim3 grid(ceil_div(N, bn), ceil_div(M, bm), 1);
     if ((flags & ARCVAE_GEMM_SPLITK) && p.act == 0) {

@@ -229,6 +229,27 @@ extern "C" int arcvae_latent_loss(const float* stats, const float* hyper, const 
     return arcvae_launch_status();
 }
 
+// Recon half of the scalars, once the decoder's CE row sums have been reduced into stats[2Z+3]
+// (arcvae_stats_set_recon, + all-reduce under data parallelism): recon = sum / (B_global*T) (mean over ALL
+// positions, Q3) and total = recon + beta*kl + collapse + lambda_prop*0 + mi_penalty (complete_vae_loss.py:76-82).
+// arcvae_latent_loss may therefore run BEFORE the decoder has finished: nothing on the encoder's backward
+// path depends on the reconstruction term (Q2).
+namespace {
+__global__ void loss_finalize_kernel(const float* __restrict__ stats, float* scalars, int Z, int T) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float recon = stats[2 * Z + 3] / (stats[2 * Z + 2] * (float)T);
+        scalars[1] = recon;
+        scalars[0] = recon + scalars[3] + scalars[4] + scalars[6] + scalars[8];
+    }
+}
+}  // namespace
+
+extern "C" int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, hipStream_t stream) {
+    if (!stats || !scalars || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, scalars, Z, T);
+    return arcvae_launch_status();
+}
+
 // Backward of the heads in two phases so the critical path (dcomb -> BPTT) does not wait for the
 // parameter-gradient GEMMs:
 //   phase 1: dcomb [B,2H] = dmu_raw . Wmu + (dlv_raw . Wlv * (1 - lh^2)) . Wlh ; leaves dlh = d(pre-tanh) in ws

@@ -8,6 +8,8 @@
 #define ARCVAE_GEMM_TANH 2
 #define ARCVAE_GEMM_SPLITK 4
 #define ARCVAE_GEMM_NO_SKINNY 8
+#define ARCVAE_GEMM_TILE64 16   /* force 64x64 tiles (tuning / tests) */
+#define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
 
 extern "C" {
 int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,

@@ -32,7 +32,9 @@ class OracleOps:
         self.cond = torch.as_tensor(cond, dtype=DT)
         self.eps = torch.as_tensor(eps, dtype=DT)
         Z = cfg.Z
-        self.stats = torch.zeros(2 * Z + 4, dtype=DT)
+        self._all = torch.zeros(2 * Z + 4, dtype=DT)
+        self.stats = self._all[:2 * Z + 3]          # latent partial sums (forward seam)
+        self.recon_stat = self._all[2 * Z + 3:]     # CE sum (reduced off the critical path)
         self.scalars = {}
         self.enc_names = [k for k in params if k.startswith("encoder.")]
         self.dec_names = [k for k in params if k.startswith("decoder.")]
@@ -58,25 +60,31 @@ class OracleOps:
 
     def forward_local(self):
         self._attached = self._local_stats()
-        self.stats.copy_(self._attached.detach())
-        self._local_detached = self.stats.clone()
+        self._all.copy_(self._attached.detach())
+        self._local_detached = self._all.clone()
+
+    def recon_local(self):
+        pass  # the oracle-side CE sum was already written by forward_local
 
     def backward_local(self):
+        """stats[:2Z+3] are global.  Gradients of the GLOBAL loss w.r.t. this rank's rows need the global latent
+        sums and B_global, but only the LOCAL CE sum (d recon / d local params = d local_ce / (B_global*T)); the
+        global CE sum is reduced later, off the critical path, exactly as on the GPU."""
         Z, T = self.cfg.Z, self.T
-        st = self.stats.detach() - self._local_detached + self._attached   # global sums, local part differentiable
-        Bg = st[2 * Z + 2]
-        mm, mv = st[:Z] / Bg, st[Z:2 * Z] / Bg
+        lat = self.stats.detach() - self._local_detached[:2 * Z + 3] + self._attached[:2 * Z + 3]
+        Bg = lat[2 * Z + 2].detach()
+        mm, mv = lat[:Z] / Bg, lat[Z:2 * Z] / Bg
         agg = -0.5 * (1.0 + torch.log(mv) - mm * mm - mv).sum()
-        mi = O.mlx_maximum(st[2 * Z] / Bg - agg, 0.0)
+        mi = O.mlx_maximum(lat[2 * Z] / Bg - agg, 0.0)
         d = HYPER["target_mi"] - mi
         dpos = torch.where(torch.zeros_like(d) > d, torch.zeros_like(d), d)
-        recon = st[2 * Z + 3] / (Bg * T)
-        kl = st[2 * Z + 1] / Bg
-        total = recon + HYPER["beta"] * kl + HYPER["lambda_collapse"] * dpos + HYPER["lambda_mi"] * dpos
-        self.scalars = dict(total=float(total), recon=float(recon), kl=float(kl), mi=float(mi))
+        kl = lat[2 * Z + 1] / Bg
+        self._latent_part = HYPER["beta"] * kl + HYPER["lambda_collapse"] * dpos + HYPER["lambda_mi"] * dpos
+        self._Bg, self._mi, self._kl = float(Bg), float(mi), float(kl)
+        local_recon = self._attached[2 * Z + 3] / (Bg * T)
         for v in self.p.values():
             v.grad = None
-        total.backward()
+        (local_recon + self._latent_part).backward()
         g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
         self.enc_grad = torch.cat([g[k].reshape(-1) for k in self.enc_names]).clone()
         self.dec_grad = torch.cat([g[k].reshape(-1) for k in self.dec_names]).clone()
@@ -91,6 +99,8 @@ class OracleOps:
         return contextlib.nullcontext()
 
     def apply_update(self):
+        recon = float(self.recon_stat[0]) / (self._Bg * self.T)   # recon_stat is global by now
+        self.scalars = dict(total=recon + float(self._latent_part), recon=recon, kl=self._kl, mi=self._mi)
         params = {k: v.detach().numpy().copy() for k, v in self.p.items()}
         grads = {}
         for names, flat in ((self.enc_names, self.enc_grad), (self.dec_names, self.dec_grad)):
