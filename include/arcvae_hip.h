@@ -58,18 +58,20 @@ int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A,
  * (MLX nn.LSTM semantics M1: gates i,f,g,o; t=0 has no recurrent term and c_0 = i*g).
  * x_tb [T,B] int32 tokens (time-major; arcvae_transpose_tokens makes it from [B,T]);
  * table0 [V,4H] = embedding . Wx_0^T + bias_0 (one arcvae_gemm_f32 call);
- * outputs hseq,cseq [L,T,B,H], gseq [L,T,B,4H] (post-activation gates, saved for BPTT). */
+ * outputs hseq,cseq [L,T,B,H], gseq [L,T,B,4H] (post-activation gates, saved for BPTT);
+ * workspaces hseq_t [L,T,B*H] and wt [(2L-1),4H*H]: k-chunk-major operand copies for the step kernels. */
 int arcvae_transpose_tokens(const int32_t* src_bt, int32_t* dst_tb, int B, int T, arcvae_stream_t stream);
 int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
-                            const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
-                            float* gseq, int B, int T, int V, int H, int L, arcvae_stream_t stream);
+                            const float* const* Wh, const float* const* bias, float* hseq, float* hseq_t,
+                            float* cseq, float* gseq, float* wt, int B, int T, int V, int H, int L,
+                            arcvae_stream_t stream);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
- * position read by models/encoder.py:106.  dG out [L,T,B,4H]; dcs, dxs ws [L,T,B,H]; wT ws [(2L-1),H,4H]. */
+ * position read by models/encoder.py:106.  dG out [L,T,B,4H]; dG_t ws [L,T,B*4H]; dcs, dxs ws [L,T,B,H]; wT ws [(2L-1),H*4H]. */
 int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
-                             const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
-                             float* dxs, float* wT, int B, int T, int H, int L, int s_begin, int s_end,
-                             arcvae_stream_t stream);
+                             const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dG_t,
+                             float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,
+                             int s_end, arcvae_stream_t stream);
 /* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,
@@ -163,6 +165,8 @@ int arcvae_transpose_batched(const float* const* src, float* const* dst, const i
                              int n, arcvae_stream_t stream);
 int arcvae_scale_inplace(float* x, long n, float s, arcvae_stream_t stream);
 int arcvae_zero(float* x, int rows, int cols, int ld, arcvae_stream_t stream);
+int arcvae_tile_weights(const float* const* src, float* const* dst, const int* cols, const int* mode, int n, int H,
+                        arcvae_stream_t stream);
 
 #ifdef __cplusplus
 }

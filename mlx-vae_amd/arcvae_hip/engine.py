@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -74,6 +75,8 @@ class Workspace:
         # encoder forward
         self.table0 = torch.empty(V, G, **f32)
         self.hseq = torch.empty(L, T, B, H, **f32)
+        self.hseq_t = torch.empty(L, T, B * H, **f32)      # k-chunk-major copy (step-kernel operand layout)
+        self.wt = torch.empty(2 * L - 1, G * H, **f32)        # k-chunk-major weights (forward layout)
         self.cseq = torch.empty(L, T, B, H, **f32)
         self.gseq = torch.empty(L, T, B, G, **f32)
         self.comb = torch.empty(B, 2 * H, **f32)
@@ -100,6 +103,7 @@ class Workspace:
             self.dlh = torch.empty(B, 2 * H, **f32)
             self.dcomb = torch.empty(B, 2 * H, **f32)
             self.dG = torch.empty(L, T, B, G, **f32)
+            self.dG_t = torch.empty(L, T, B * G, **f32)       # k-chunk-major copy
             self.dcs = torch.empty(L, T, B, H, **f32)
             self.dxs = torch.empty(L, T, B, H, **f32)
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
@@ -132,8 +136,8 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
     wx, _k1 = _layer_ptrs(enc, d.L, "Wx", skip0=True)
     wh, _k2 = _layer_ptrs(enc, d.L, "Wh")
     bs, _k3 = _layer_ptrs(enc, d.L, "bias", skip0=True)
-    call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.cseq),
-         ptr(ws.gseq), B, T, d.V, d.H, d.L, s)
+    call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
+         ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), B, T, d.V, d.H, d.L, s)
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
          ptr(enc.p("condition_fc.bias")), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
@@ -230,7 +234,7 @@ class EncoderBackwardPlan:
     completes its time range.  Chunks shrink geometrically so the part of the weight-gradient work that
     cannot overlap the sweep (the last chunk) is small."""
 
-    FRACTIONS = (0.3, 0.6, 0.85, 1.0)
+    FRACTIONS = tuple(float(f) for f in os.environ.get("ARCVAE_BPTT_CHUNKS", "0.3,0.6,0.85,1.0").split(","))
 
     def __init__(self, enc: ParamStore, ws: Workspace, d: ModelDims):
         self.enc, self.ws, self.d = enc, ws, d
@@ -262,7 +266,8 @@ class EncoderBackwardPlan:
     def sweep(self, s0: int, s1: int) -> None:  # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
-             2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1, stream_ptr())
+             2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
+             stream_ptr())
 
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool) -> None:
         enc, ws, d = self.enc, self.ws, self.d
@@ -440,21 +445,25 @@ class StepEngine:
         """stats[2Z+3] = sum of this process's CE row sums (after the decoder's TF walk)."""
         main = torch.cuda.current_stream()
         main.wait_event(self.ev_chain)
-        run("recon", lambda: call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z,
-                                  stream_ptr()), main)
+        run("recon", lambda: self._recon(ws), main)
 
-    def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline) -> None:
-        """recon/total scalars from the (global) CE sum, join the side stream, both Adam updates."""
+    def _recon(self, ws: Workspace) -> None:
+        call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z, stream_ptr())
+
+    def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline, with_recon: bool = False) -> None:
+        """[CE sum ->] recon/total scalars, join the side stream, both Adam updates: one segment."""
         main = torch.cuda.current_stream()
         main.wait_stream(self.side)
 
         def fin():
+            if with_recon:
+                self._recon(ws)
             call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
             if update:
                 adam_update(self.dec, lr)
                 adam_update(self.enc, lr)
 
-        run("finish" if update else "finish_noupdate", fin, main)
+        run(("finish" if update else "finish_noupdate") + ("_r" if with_recon else ""), fin, main)
 
     def _enqueue_step(self, ws: Workspace, lr: float, global_rows: int, update: bool, run=_inline) -> None:
         """Single-process step.  Host enqueue order = GPU priority: encoder forward first (the critical chain),
@@ -465,8 +474,7 @@ class StepEngine:
         self.enqueue_encoder_forward(ws, run)
         self.enqueue_decoder(ws, global_rows, run, wait_current=False)
         self.enqueue_backward(ws, run)
-        self.enqueue_recon(ws, run)
-        self.enqueue_finish(ws, lr, update, run)
+        self.enqueue_finish(ws, lr, update, run, with_recon=True)
 
     # ---- public API --------------------------------------------------------------------------------
     def forward_loss(self, x, cond, eps, coins, **hyper) -> Dict[str, torch.Tensor]:

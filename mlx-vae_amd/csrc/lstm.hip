@@ -25,14 +25,15 @@
 namespace {
 
 struct FwdJob {
-    const float* xin;    // [B,H]   h^{l-1}_t, or null for layer 0
-    const float* Wx;     // [4H,H]
-    const float* hprev;  // [B,H]   h^l_{t-1}, or null at t == 0 (MLX: hidden=None skips the term)
-    const float* Wh;     // [4H,H]
+    const float* xin;    // tiled [H/16][B][16]  h^{l-1}_t, or null for layer 0
+    const float* Wx;     // tiled+permuted [H/16][4H][16]  (arcvae_tile_weights mode 0)
+    const float* hprev;  // tiled [H/16][B][16]  h^l_{t-1}, or null at t == 0 (MLX: hidden=None skips the term)
+    const float* Wh;     // tiled+permuted [H/16][4H][16]
     const float* pre;    // layer 0: table0 [V,4H] (bias folded in); else bias [4H]
     const int32_t* tok;  // layer 0: tokens of this step [B]; else null
     const float* cprev;  // [B,H] or null at t == 0 (MLX: cell=None -> c = i*g)
     float* h;            // [B,H]
+    float* ht;           // tiled copy [H/16][B][16] (operand of the next launches)
     float* c;            // [B,H]
     float* gates;        // [B,4H] post-activation i,f,g,o (saved for BPTT)
 };
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     const int r0 = blockIdx.y * 16, u0 = blockIdx.x * 4;
     const int arow = min(r0 + (lane & 15), B - 1);
     const int jc = lane & 15;
-    const long wrow = (long)(jc >> 2) * H + u0 + (jc & 3);  // gate-major weight row of tile column jc
+    const int wrow = blockIdx.x * 16 + jc;  // permuted weight row of tile column jc (gate = jc>>2, unit = u0+(jc&3))
     const bool s1 = j.xin != nullptr, s2 = j.hprev != nullptr;
     // Epilogue operands are requested FIRST (token -> table row is a dependent pair of loads, c_{t-1}
     // another cold line): their round trip then overlaps the operand loads instead of following the MFMAs.
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     float cprev_v = 0.f;
     if (tid < 64 && j.cprev) cprev_v = j.cprev[hb];
     SkinnyFrag<CH> f1, f2;
-    if (s1) skinny_load<CH>(f1, j.xin, (long)arow * H, j.Wx, wrow * H, wave, lane);
-    if (s2) skinny_load<CH>(f2, j.hprev, (long)arow * H, j.Wh, wrow * H, wave, lane);
+    if (s1) skinny_load_tiled<CH>(f1, j.xin, arow, B, j.Wx, wrow, 4 * H, wave, lane);
+    if (s2) skinny_load_tiled<CH>(f2, j.hprev, arow, B, j.Wh, wrow, 4 * H, wave, lane);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (s1) skinny_mfma<CH>(f1, acc0, acc1);
     if (s2) skinny_mfma<CH>(f2, acc0, acc1);
@@ -89,7 +90,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
         const float i = act[crow * 16 + cu], f = act[crow * 16 + 4 + cu], g = act[crow * 16 + 8 + cu],
                     o = act[crow * 16 + 12 + cu];
         const float c = j.cprev ? f * cprev_v + i * g : i * g;
-        j.h[hb] = o * tanhf(c);
+        const float hv = o * tanhf(c);
+        const int unit = u0 + cu;
+        j.h[hb] = hv;
+        j.ht[((long)(unit >> 4) * B + (r0 + crow)) * 16 + (unit & 15)] = hv;
         j.c[hb] = c;
     }
 }
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
 // makes every block move the same 128 KB and spreads a launch over more CUs: the step is bound by how fast
 // a CU can pull its operands (profiles/r01: 10.3 us per launch with the fused two-source job), not by MFMA.
 struct BwdJob {
-    const float* src;     // [B,4H]  or null (cell at t == T-1: no recurrent term)
-    const float* WT;      // [H,4H]
+    const float* src;     // tiled [4H/16][B][16]  or null (cell at t == T-1: no recurrent term)
+    const float* WT;      // tiled [4H/16][H][16]  (arcvae_tile_weights mode 1: W^T)
     const float* ext;     // [B,ext_ld] added to dh (cell) or null
     const float* gates;   // [B,4H] i,f,g,o at (l,t)            (cell)
     const float* c;       // [B,H] c_t                          (cell)
@@ -111,6 +115,7 @@ struct BwdJob {
     const float* dcin;    // [B,H] dc_{t+1} * f_{t+1} or null   (cell)
     float* dcout;         // [B,H] dc_t * f_t                   (cell)
     float* out;           // cell: dG [B,4H];  xproj: dX [B,H]
+    float* outt;          // cell: tiled copy of dG [4H/16][B][16] (operand of the next launches)
     int ext_ld;
     int kind;
 };
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     const int B = a.B, H = a.H, G = 4 * a.H;
     const int r0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
     const int arow = min(r0 + (lane & 15), B - 1);
-    const long wrow = u0 + (lane & 15);
+    const int wrow = u0 + (lane & 15);
     const bool cell = j.kind == 0;
     // epilogue operands first: their cold round trip overlaps the operand loads (see the forward kernel)
     const int erow = tid >> 4, ecol = tid & 15;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (j.src) {
         SkinnyFrag<CH> f;
-        skinny_load<CH>(f, j.src, (long)arow * G, j.WT, wrow * G, wave, lane);
+        skinny_load_tiled<CH>(f, j.src, arow, B, j.WT, wrow, H, wave, lane);
         skinny_mfma<CH>(f, acc0, acc1);
     }
     skinny_store_partial_n(red, acc0, acc1, wave, lane);
@@ -171,6 +176,13 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
             dp[H] = d_f;
             dp[2 * H] = d_g;
             dp[3 * H] = d_o;
+            // tiled copy: contraction index jj = gate*H + unit -> [(jj/16)][b][jj%16]; H % 16 == 0 so jj%16 = unit%16
+            float* tp = j.outt + ((long)(unit >> 4) * B + eb) * 16 + (unit & 15);
+            const long gs = (long)(H >> 4) * B * 16;  // one gate block of H contraction indices
+            tp[0] = d_i;
+            tp[gs] = d_f;
+            tp[2 * gs] = d_g;
+            tp[3 * gs] = d_o;
         }
     }
 }
@@ -205,17 +217,32 @@ inline bool hidden_ok(int H) { return H > 0 && (H % 64) == 0 && H <= 512; }
 //   x_tb   [T,B] tokens (time-major)          table0 [V,4H] = emb . Wx_0^T + bias_0
 //   Wx[l]  [4H,H] (l >= 1), Wh[l] [4H,H], bias[l] [4H] (l >= 1): HOST arrays of device pointers
 //   hseq/cseq [L,T,B,H], gseq [L,T,B,4H] outputs (gseq = post-activation i,f,g,o)
+//   hseq_t [L,T,B*H] workspace: k-chunk-major copy of every h slab (operand layout of the step kernels)
+//   wt     [(2L-1),4H*H] workspace: k-chunk-major weight copies, refreshed here (weights change every step)
 //   hidden_dim: multiple of 64, <= 512.
 extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq,
-                                       float* cseq, float* gseq, int B, int T, int V, int H, int L,
-                                       hipStream_t stream) {
-    if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq) return ARCVAE_ERR_ARG;
+                                       float* hseq_t, float* cseq, float* gseq, float* wt, int B, int T, int V,
+                                       int H, int L, hipStream_t stream) {
+    if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !hseq_t || !cseq || !gseq || !wt) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || V <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
+    const long wsz = (long)H * 4 * H;
+    {   // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz
+        const float* src[16];
+        float* dst[16];
+        int cols[16], mode[16];
+        int n = 0;
+        for (int l = 0; l < L; ++l) {
+            src[n] = Wh[l]; dst[n] = wt + l * wsz; cols[n] = H; mode[n] = 0; ++n;
+            if (l > 0) { src[n] = Wx[l]; dst[n] = wt + (L + l - 1) * wsz; cols[n] = H; mode[n] = 0; ++n; }
+        }
+        const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
+        if (rc != ARCVAE_OK) return rc;
+    }
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
         a.B = B; a.H = H; a.V = V;
@@ -224,14 +251,15 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             const int t = s - l;
             if (t < 0 || t >= T) continue;
             FwdJob& j = a.job[nj++];
-            j.xin = l > 0 ? hseq + (l - 1) * lH + t * sH : nullptr;
-            j.Wx = l > 0 ? Wx[l] : nullptr;
-            j.hprev = t > 0 ? hseq + l * lH + (t - 1) * sH : nullptr;
-            j.Wh = Wh[l];
+            j.xin = l > 0 ? hseq_t + (l - 1) * lH + t * sH : nullptr;
+            j.Wx = l > 0 ? wt + (L + l - 1) * wsz : nullptr;
+            j.hprev = t > 0 ? hseq_t + l * lH + (t - 1) * sH : nullptr;
+            j.Wh = wt + l * wsz;
             j.pre = l > 0 ? bias[l] : table0;
             j.tok = l > 0 ? nullptr : x_tb + (long)t * B;
             j.cprev = t > 0 ? cseq + l * lH + (t - 1) * sH : nullptr;
             j.h = hseq + l * lH + t * sH;
+            j.ht = hseq_t + l * lH + t * sH;
             j.c = cseq + l * lH + t * sH;
             j.gates = gseq + l * lG + t * sG;
         }
@@ -245,15 +273,15 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
 // BPTT for the stack.  Only h_{T-1} of the top layer receives an external gradient
 // (models/encoder.py:106).  Produces dG [L,T,B,4H] (pre-activation gate gradients); weight
 // gradients are formed from dG by arcvae_enc_lstm_wgrad.
-//   dcs, dxs  workspaces [L,T,B,H];  wT workspace [(2L-1),H,4H] (transposed Wh_l, Wx_l copies, refreshed
-//   when s_begin == 0).  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
+//   dcs, dxs  workspaces [L,T,B,H];  dG_t workspace [L,T,B*4H] (k-chunk-major copy of dG);  wT workspace
+//   [(2L-1),H*4H] (k-chunk-major Wh_l^T, Wx_l^T copies, refreshed when s_begin == 0).  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
 //   Schedule: cell(l,t) at launch (T-1-t) + 2(L-1-l); xproj_l(t) (dX_l[t] = dG^{l+1}_t . Wx_{l+1}) one launch earlier.
 //   After launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).
 extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
-                                        float* dcs, float* dxs, float* wT, int B, int T, int H, int L,
-                                        int s_begin, int s_end, hipStream_t stream) {
-    if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
+                                        float* dG_t, float* dcs, float* dxs, float* wT, int B, int T, int H,
+                                        int L, int s_begin, int s_end, hipStream_t stream) {
+    if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
     const int S = T + 2 * (L - 1);
@@ -261,18 +289,18 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
     const long wsz = (long)H * 4 * H;
-    // transposed weight copies: WhT[l] at wT + l*wsz, WxT[l] (l>=1) at wT + (L + l - 1)*wsz
+    // tiled transposed weight copies: WhT[l] at wT + l*wsz, WxT[l] (l>=1) at wT + (L + l - 1)*wsz
     if (s_begin == 0) {
         const float* src[16];
         float* dst[16];
-        int rows[16], cols[16];
+        int cols[16], mode[16];
         int n = 0;
         for (int l = 0; l < L; ++l) {
             if (!Wh[l] || (l > 0 && !Wx[l])) return ARCVAE_ERR_ARG;
-            src[n] = Wh[l]; dst[n] = wT + l * wsz; rows[n] = 4 * H; cols[n] = H; ++n;
-            if (l > 0) { src[n] = Wx[l]; dst[n] = wT + (L + l - 1) * wsz; rows[n] = 4 * H; cols[n] = H; ++n; }
+            src[n] = Wh[l]; dst[n] = wT + l * wsz; cols[n] = H; mode[n] = 1; ++n;
+            if (l > 0) { src[n] = Wx[l]; dst[n] = wT + (L + l - 1) * wsz; cols[n] = H; mode[n] = 1; ++n; }
         }
-        const int rc = arcvae_transpose_batched(src, dst, rows, cols, n, stream);
+        const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
     }
     for (int s = s_begin; s < s_end; ++s) {
@@ -286,7 +314,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 BwdJob& j = a.job[nj++];
                 const bool top = (l == L - 1), last = (t == T - 1);
                 j.kind = 0;
-                j.src = last ? nullptr : dG + l * lG + (t + 1) * sG;
+                j.src = last ? nullptr : dG_t + l * lG + (t + 1) * sG;
                 j.WT = wT + l * wsz;
                 if (top) { j.ext = last ? dh_top : nullptr; j.ext_ld = ld_dh_top; }
                 else { j.ext = dxs + l * lH + t * sH; j.ext_ld = H; }
@@ -296,16 +324,18 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 j.dcin = last ? nullptr : dcs + l * lH + (t + 1) * sH;
                 j.dcout = dcs + l * lH + t * sH;
                 j.out = dG + l * lG + t * sG;
+                j.outt = dG_t + l * lG + t * sG;
             }
             const int tx = T - 1 - (s + 1 - skew);     // xproj_l(tx): feeds cell(l, tx) at the next launch
             if (l < L - 1 && tx >= 0 && tx < T) {
                 BwdJob& j = a.job[nj++];
                 j.kind = 1;
-                j.src = dG + (l + 1) * lG + tx * sG;
+                j.src = dG_t + (l + 1) * lG + tx * sG;
                 j.WT = wT + (L + l) * wsz;             // WxT[l+1]
                 j.ext = nullptr; j.ext_ld = H;
                 j.gates = nullptr; j.c = nullptr; j.cprev = nullptr; j.dcin = nullptr; j.dcout = nullptr;
                 j.out = dxs + l * lH + tx * sH;
+                j.outt = nullptr;
             }
         }
         if (nj == 0) continue;

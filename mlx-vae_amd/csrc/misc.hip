@@ -51,6 +51,36 @@ __global__ __launch_bounds__(256) void transpose_kernel(TrJobs j) {
     }
 }
 
+// ---- k-chunk-major re-layout of LSTM weights for the step kernels (skinny.h: skinny_load_tiled) ---------
+// mode 0 (forward):  W [4H, K] -> dst[(k/16)][perm(r)][k%16], perm(gate*H + unit) = (unit>>2)*16 + gate*4 + (unit&3)
+//                    (the 16 gate columns of a 4-unit forward block become 16 consecutive rows)
+// mode 1 (backward): W [4H, H] -> dst[(j/16)][unit][j%16]   (W^T, contraction index j = gate row, tiled)
+struct TileJobs {
+    const float* src[16];
+    float* dst[16];
+    int cols[16];  // K (mode 0) or H (mode 1)
+    int mode[16];
+};
+__global__ __launch_bounds__(256) void tile_weights_kernel(TileJobs j, int H) {
+    const int z = blockIdx.y;
+    const int K = j.cols[z];
+    const long n = (long)4 * H * K;
+    const float* __restrict__ src = j.src[z];
+    float* dst = j.dst[z];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / K), k = (int)(i - (long)r * K);
+        long o;
+        if (j.mode[z] == 0) {
+            const int gate = r / H, unit = r - gate * H;
+            const int rp = (unit >> 2) * 16 + gate * 4 + (unit & 3);
+            o = ((long)(k >> 4) * 4 * H + rp) * 16 + (k & 15);
+        } else {
+            o = ((long)(r >> 4) * K + k) * 16 + (r & 15);
+        }
+        dst[o] = src[i];
+    }
+}
+
 // ---- segment sum: out[seg[r], :] += X[r, :] --------------------------------------------
 // Block = 64 columns x 4 row lanes over a 256-row chunk; per-block [nseg][64] table in LDS
 // (ds_add_f32), flushed with one global f32 atomic per touched entry.
@@ -158,6 +188,19 @@ extern "C" int arcvae_transpose_batched(const float* const* src, float* const* d
     for (int i = n; i < 16; ++i) { j.src[i] = nullptr; j.dst[i] = nullptr; j.rows[i] = 0; j.cols[i] = 0; }
     dim3 grid(ceil_div(maxc, 32), ceil_div(maxr, 32), n);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, j);
+    return arcvae_launch_status();
+}
+
+extern "C" int arcvae_tile_weights(const float* const* src, float* const* dst, const int* cols, const int* mode,
+                                   int n, int H, hipStream_t stream) {
+    if (n <= 0 || n > 16 || H <= 0) return ARCVAE_ERR_ARG;
+    TileJobs j;
+    for (int i = 0; i < 16; ++i) {
+        const int k = i < n ? i : 0;
+        if (!src[k] || !dst[k] || cols[k] <= 0 || (cols[k] % 16) != 0) return ARCVAE_ERR_ARG;
+        j.src[i] = src[k]; j.dst[i] = dst[k]; j.cols[i] = cols[k]; j.mode[i] = mode[k];
+    }
+    hipLaunchKernelGGL(tile_weights_kernel, dim3(256, n), dim3(256), 0, stream, j, H);
     return arcvae_launch_status();
 }
 

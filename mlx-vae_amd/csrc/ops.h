@@ -24,6 +24,9 @@ int arcvae_transpose_batched(const float* const* src, float* const* dst, const i
 // out[seg[r], :] += X[r, :]   (out is [nseg, cols], pre-initialised by the caller)
 int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int rows, int nseg, int cols,
                              float* out, hipStream_t stream);
+// k-chunk-major copies of LSTM weights (mode 0: forward layout, 1: transposed/backward layout); HOST arrays
+int arcvae_tile_weights(const float* const* src, float* const* dst, const int* cols, const int* mode, int n, int H,
+                        hipStream_t stream);
 // x[r*ld + c] = 0
 int arcvae_zero(float* x, int rows, int cols, int ld, hipStream_t stream);
 // dst[t*B + b] = src[b*T + t]

@@ -87,6 +87,71 @@ __global__ __launch_bounds__(256) void step_kernel(Args a) {
     }
 }
 
+// TILED + 32 gate columns per block (A fragment reused for two W fragments): 1 block per CU at B=64, 2 jobs
+template <int CH>
+__global__ __launch_bounds__(256) void step_kernel_bn32(Args a) {
+    __shared__ float red[2 * 4 * 256];
+    __shared__ float act[512];
+    const Job& j = a.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H;
+    const int r0 = blockIdx.y * 16, u0 = blockIdx.x * 8;
+    const int arow = min(r0 + (lane & 15), B - 1);
+    const int jc = lane & 15;
+    const int q4 = (lane >> 4) * 4;
+    const long wr = (long)blockIdx.x * 32 + jc;
+    float4 a1[CH], a2[CH], w1a[CH], w1b[CH], w2a[CH], w2b[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const long kc = wave * CH + c;
+        a1[c] = *reinterpret_cast<const float4*>(j.xin + (kc * B + arow) * 16 + q4);
+        w1a[c] = *reinterpret_cast<const float4*>(j.Wx + (kc * 4 * H + wr) * 16 + q4);
+        w1b[c] = *reinterpret_cast<const float4*>(j.Wx + (kc * 4 * H + wr + 16) * 16 + q4);
+        a2[c] = *reinterpret_cast<const float4*>(j.hprev + (kc * B + arow) * 16 + q4);
+        w2a[c] = *reinterpret_cast<const float4*>(j.Wh + (kc * 4 * H + wr) * 16 + q4);
+        w2b[c] = *reinterpret_cast<const float4*>(j.Wh + (kc * 4 * H + wr + 16) * 16 + q4);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, bcc0 = {0.f, 0.f, 0.f, 0.f}, bcc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        { SKINNY_MFMA4(a1[c], w1a[c]) }
+        { SKINNY_MFMA4(a2[c], w2a[c]) }
+    }
+    skinny_store_partial_n(red, acc0, acc1, wave, lane);
+    acc0 = bcc0; acc1 = bcc1;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        { SKINNY_MFMA4(a1[c], w1b[c]) }
+        { SKINNY_MFMA4(a2[c], w2b[c]) }
+    }
+    skinny_store_partial_n(red + 1024, acc0, acc1, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = tid >> 4, col = tid & 15;
+        const int b = r0 + row;
+        const int gcol = (col >> 2) * H + u0 + h * 4 + (col & 3);
+        const float v = skinny_reduced_n<4>(red + h * 1024, row, col) + j.pre[gcol];
+        const float av = ((col >> 2) == 2) ? tanhf(v) : sigmoidf_acc(v);
+        act[h * 256 + tid] = av;
+        if (b < B) j.gates[(long)b * 4 * H + gcol] = av;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int h = tid >> 6, t = tid & 63;
+        const int row = t >> 2, u = t & 3;
+        const int b = r0 + row;
+        if (b < B) {
+            const float* ac = act + h * 256 + row * 16;
+            const float i = ac[u], f = ac[4 + u], g = ac[8 + u], o = ac[12 + u];
+            const long hb = (long)b * H + u0 + h * 4 + u;
+            const float c = f * j.cprev[hb] + i * g;
+            j.h[hb] = o * tanhf(c);
+            j.c[hb] = c;
+        }
+    }
+}
+
 template <int MODE, bool TILED = false>
 int run(const char* name, int B, int H, int T, int njobs, int blocks_x_div, float* buf, hipStream_t s) {
     const long sH = (long)B * H, sG = (long)B * 4 * H;
@@ -109,7 +174,8 @@ int run(const char* name, int B, int H, int T, int njobs, int blocks_x_div, floa
         }
         for (int k = njobs; k < 8; ++k) a.job[k] = a.job[0];
         dim3 grid(H / 4 / blocks_x_div, (B + 15) / 16, njobs);
-        hipLaunchKernelGGL((step_kernel<MODE, 4, TILED>), grid, dim3(256), 0, s, a);
+        if (MODE == 9) { grid.x = H / 8; hipLaunchKernelGGL((step_kernel_bn32<4>), grid, dim3(256), 0, s, a); }
+        else hipLaunchKernelGGL((step_kernel<(MODE == 9 ? 3 : MODE), 4, TILED>), grid, dim3(256), 0, s, a);
     }
     CK(hipStreamEndCapture(s, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -145,6 +211,8 @@ int main() {
         run<2, true>("TILED loads + mfma + lds", B, H, T, 2, 1, buf, s);
         run<3, true>("TILED full", B, H, T, 2, 1, buf, s);
         run<3, true>("TILED full, 1 job", B, H, T, 1, 1, buf, s);
+        run<9, true>("TILED BN=32 full", B, H, T, 2, 1, buf, s);
+        run<9, true>("TILED BN=32 full, 1 job", B, H, T, 1, 1, buf, s);
     }
     return 0;
 }
