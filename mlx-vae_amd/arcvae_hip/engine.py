@@ -399,7 +399,7 @@ class StepEngine:
 
     # ---- the phases of a step (data-parallel collectives go between them, dp.py) ------------------------
     def enqueue_decoder(self, ws: Workspace, global_rows: int, run=_inline, backward: bool = True,
-                        wait_current: bool = True) -> None:
+                        wait_current: bool = True, split_events: bool = True) -> None:
         """Dense decoder on the side stream: forward + TF walk + CE row sums (ev_chain), then its whole backward
         (ev_dec_bwd).  Independent of the encoder (Q2); it only has to follow the input copies."""
         d = self.d
@@ -412,10 +412,18 @@ class StepEngine:
             decoder_forward_dense(self.dec, ws, d)
             decoder_chain(ws, d)
 
+        def dec_bwd():
+            decoder_backward(self.dec, ws, d, 1.0 / (global_rows * ws.T))
+
+        if backward and not split_events:  # single process: one side-stream segment (one graph launch less)
+            run("dec_all", lambda: (dec_fwd(), dec_bwd()), self.side)
+            self.ev_chain.record(self.side)
+            self.ev_dec_bwd.record(self.side)
+            return
         run("dec_fwd", dec_fwd, self.side)
         self.ev_chain.record(self.side)
         if backward:
-            run("dec_bwd", lambda: decoder_backward(self.dec, ws, d, 1.0 / (global_rows * ws.T)), self.side)
+            run("dec_bwd", dec_bwd, self.side)
             self.ev_dec_bwd.record(self.side)
 
     def _enc_fwd(self, ws: Workspace, backward: bool) -> None:
@@ -471,8 +479,12 @@ class StepEngine:
         fused loss + dcomb + BPTT segments with the weight-gradient chunks on aux; the decoder is only joined at
         the very end (nothing on the encoder's backward path needs the reconstruction term)."""
         self.side.wait_stream(torch.cuda.current_stream())   # the decoder only has to follow the input copies
-        self.enqueue_encoder_forward(ws, run)
-        self.enqueue_decoder(ws, global_rows, run, wait_current=False)
+        if os.environ.get("ARCVAE_DECODER_FIRST", "1") == "1":
+            self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)
+            self.enqueue_encoder_forward(ws, run)
+        else:
+            self.enqueue_encoder_forward(ws, run)
+            self.enqueue_decoder(ws, global_rows, run, wait_current=False)
         self.enqueue_backward(ws, run)
         self.enqueue_finish(ws, lr, update, run, with_recon=True)
 
