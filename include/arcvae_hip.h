@@ -37,7 +37,8 @@ extern "C" {
 #define ARCVAE_GEMM_SPLITK 4     /* allow split-K with f32 atomics             */
 #define ARCVAE_GEMM_NO_SKINNY 8
 #define ARCVAE_GEMM_TILE64 16   /* force 64x64 tiles (tuning / tests) */
-#define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */  /* force the tile kernel                      */
+#define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
+#define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */  /* force the tile kernel                      */
 
 typedef void* arcvae_stream_t; /* hipStream_t */
 
@@ -63,15 +64,15 @@ int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A,
 int arcvae_transpose_tokens(const int32_t* src_bt, int32_t* dst_tb, int B, int T, arcvae_stream_t stream);
 int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                             const float* const* Wh, const float* const* bias, float* hseq, float* hseq_t,
-                            float* cseq, float* gseq, float* wt, int B, int T, int V, int H, int L,
-                            arcvae_stream_t stream);
+                            float* cseq, float* gseq, float* wt, float* wT_bwd /* optional */, int B, int T, int V,
+                            int H, int L, arcvae_stream_t stream);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
  * position read by models/encoder.py:106.  dG out [L,T,B,4H]; dG_t ws [L,T,B*4H]; dcs, dxs ws [L,T,B,H]; wT ws [(2L-1),H*4H]. */
 int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                              const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dG_t,
                              float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,
-                             int s_end, arcvae_stream_t stream);
+                             int s_end, int retile, arcvae_stream_t stream);
 /* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,
@@ -80,7 +81,8 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
                           const float* dG, float* dtable_ws, float* dEmb, float* const* dWx,
                           float* const* dWh, float* const* dbias, int B, int T, int V, int E, int H, int L,
-                          int t_lo, int t_hi, int first, int last, arcvae_stream_t stream);
+                          int t_lo, int t_hi, int first, int last, int parts /* 1 layers | 2 token table */,
+                          arcvae_stream_t stream);
 
 /* ---- encoder heads + reparameterisation + latent loss ----------------------------------------
  * models/encoder.py:106-130 (condition_fc, fc_mu, fc_logvar_hidden, fc_logvar, tanh bounds),

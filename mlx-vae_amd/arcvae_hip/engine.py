@@ -137,7 +137,8 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
     wh, _k2 = _layer_ptrs(enc, d.L, "Wh")
     bs, _k3 = _layer_ptrs(enc, d.L, "bias", skip0=True)
     call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
-         ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), B, T, d.V, d.H, d.L, s)
+         ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), ptr(ws.wT) if hasattr(ws, "wT") else C.c_void_p(0), B, T, d.V,
+         d.H, d.L, s)
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
          ptr(enc.p("condition_fc.bias")), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
@@ -267,17 +268,17 @@ class EncoderBackwardPlan:
         ws, d = self.ws, self.d
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
              2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
-             stream_ptr())
+             0, stream_ptr())  # retile = 0: the forward of this step already wrote the BPTT weight layouts
 
-    def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool) -> None:
+    def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3) -> None:
         enc, ws, d = self.enc, self.ws, self.d
         call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
              ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(enc.g("embedding.weight")), self._dwx[0], self._dwh[0],
-             self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), stream_ptr())
+             self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), parts, stream_ptr())
 
 
 def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
-                     run=_inline, prologue=None, after_first=None) -> None:
+                     run=_inline, prologue=None, after_first=None, aux2: Optional[torch.cuda.Stream] = None) -> None:
     """Backward of heads + LSTM stack on (current stream, aux).  `prologue` (optional) is enqueued at the head
     of the first main-stream segment (used to fuse encoder forward + loss into it); `after_first` (optional) is
     called on the host right after that first segment has been enqueued (the decoder is enqueued there: early
@@ -304,10 +305,12 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
                 plan.heads(1)
             plan.sweep(s0, s1)
 
-        def aux_seg(c=c, t_lo=t_lo, t_hi=t_hi, first=first, last=last):
+        split_tail = last and aux2 is not None  # the last chunk is the exposed tail: run its two halves side by side
+
+        def aux_seg(c=c, t_lo=t_lo, t_hi=t_hi, first=first, last=last, split_tail=split_tail):
             if c == 0:
                 plan.heads(2)
-            plan.wgrad(t_lo, t_hi, first, last)
+            plan.wgrad(t_lo, t_hi, first, last, 1 if split_tail else 3)
 
         run(f"main{c}", main_seg, main)
         if c == 0 and after_first:
@@ -315,8 +318,14 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
         ev = torch.cuda.Event()
         ev.record(main)
         aux.wait_event(ev)
+        if split_tail:
+            aux2.wait_stream(aux)  # the token table accumulates across chunks: follow the earlier chunks
+            aux2.wait_event(ev)
+            run(f"aux2_{c}", lambda a=t_lo, b=t_hi, f=first, l=last: plan.wgrad(a, b, f, l, 2), aux2)
         run(f"aux{c}", aux_seg, aux)
     main.wait_stream(aux)
+    if aux2 is not None:
+        main.wait_stream(aux2)
 
 
 def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
@@ -343,8 +352,12 @@ class StepEngine:
         self._ws: Dict[Tuple[int, int, bool], Workspace] = {}
         self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
         self._runners: Dict[Tuple, SegmentRunner] = {}
-        self.side = torch.cuda.Stream(device=self.device)
-        self.aux = torch.cuda.Stream(device=self.device)
+        # the critical chain runs on the caller's stream; decoder and weight-gradient GEMMs on LOWER-priority
+        # streams so their blocks are dispatched behind the latency-bound step kernels
+        lo = int(os.environ.get("ARCVAE_SIDE_PRIORITY", "0"))
+        self.side = torch.cuda.Stream(device=self.device, priority=lo)
+        self.aux = torch.cuda.Stream(device=self.device, priority=lo)
+        self.aux2 = torch.cuda.Stream(device=self.device, priority=lo)
         self.hyper_host = dict(beta=0.4, lambda_collapse=0.01, lambda_mi=0.0, target_mi=4.85, free_bits=0.5)
         self.mode = "segments"
         self.ev_chain = torch.cuda.Event()
@@ -447,7 +460,8 @@ class StepEngine:
                 self._enc_fwd(ws, True)
             latent_loss(ws, self.d, fb, True)
 
-        encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue, after_first=after_first)
+        encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue, after_first=after_first,
+                         aux2=self.aux2)
 
     def enqueue_recon(self, ws: Workspace, run=_inline) -> None:
         """stats[2Z+3] = sum of this process's CE row sums (after the decoder's TF walk)."""

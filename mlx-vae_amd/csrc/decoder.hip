@@ -449,7 +449,8 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
         hipLaunchKernelGGL(dec_wc_reduce_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, stream, wcpart, dWx[0],
                            V, G, E, C);
     // dEmb += dTableD . Wx0[:, :E]        (M=V, N=E, K=4H; B operand = Wx0 [4H, E+C] row-major, ld E+C)
-    rc = arcvae_gemm_f32(0, 0, V, E, G, dtableD, G, Wx[0], E + C, dEmb, E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
+    rc = arcvae_gemm_f32(0, 0, V, E, G, dtableD, G, Wx[0], E + C, dEmb, E, nullptr,
+                         ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_NO_SKINNY, stream);
     if (rc) return rc;
     // dWx0[:, :E] += dTableD^T . Emb      (M=4H, N=E, K=V; C has ld E+C)
     rc = arcvae_gemm_f32(1, 0, G, E, V, dtableD, G, emb, E, dWx[0], E + C, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);

@@ -28,7 +28,7 @@ struct GemmP {
     int M, N, K;
     int lda, ldb, ldc;
     int accumulate;  // C += result (non-split path)
-    int act;         // 0 none, 1 tanh
+    int act;         // 0 none, 1 tanh, 2 d-tanh: C = acc * (1 - T^2) with T = `bias` read as an [M,ldc] matrix
     int kchunk;      // K range per blockIdx.z (multiple of 16)
 };
 
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
         for (int j = 0; j < NT; ++j) {
             const int col = n0 + wn * WN + j * 32 + (lane & 31);
             if (col >= p.N) continue;
-            const float bv = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.f;
+            const float bv = (p.bias && p.act != 2 && blockIdx.z == 0) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
                 } else {
                     if (p.accumulate) v += *c;
                     if (p.act == 1) v = tanhf(v);
+                    if (p.act == 2) { const float t = p.bias[(long)row * p.ldc + col]; v *= (1.0f - t * t); }
                     *c = v;
                 }
             }
@@ -206,10 +207,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
     const int gr = m0 + row, gc = n0 + col;
     if (gr < p.M && gc < p.N) {
         float v = skinny_reduced(red, row, col);
-        if (p.bias) v += p.bias[gc];
+        if (p.bias && p.act != 2) v += p.bias[gc];
         float* c = p.C + (long)gr * p.ldc + gc;
         if (p.accumulate) v += *c;
         if (p.act == 1) v = tanhf(v);
+        if (p.act == 2) { const float t = p.bias[(long)gr * p.ldc + gc]; v *= (1.0f - t * t); }
         *c = v;
     }
 }
@@ -247,7 +249,8 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     p.A = A; p.B = B; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.accumulate = (flags & ARCVAE_GEMM_ACCUMULATE) ? 1 : 0;
-    p.act = (flags & ARCVAE_GEMM_TANH) ? 1 : 0;
+    p.act = (flags & ARCVAE_GEMM_TANH) ? 1 : ((flags & ARCVAE_GEMM_DTANH) ? 2 : 0);
+    if (p.act == 2 && (!bias || p.accumulate)) return ARCVAE_ERR_ARG;
     p.kchunk = ((K + BK - 1) / BK) * BK;
 
     const bool ak = !transA, bk = transB != 0;

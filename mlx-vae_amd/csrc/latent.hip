@@ -21,9 +21,10 @@ namespace {
 __global__ __launch_bounds__(256) void build_comb_kernel(const float* __restrict__ hT,
                                                          const float* __restrict__ cond,
                                                          const float* __restrict__ Wc,
-                                                         const float* __restrict__ bc, float* comb, int B, int H,
-                                                         int C) {
+                                                         const float* __restrict__ bc, float* comb, float* stats,
+                                                         int nstats, int B, int H, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nstats) stats[idx] = 0.f;  // zero the partial-sum seam here: one launch less on the critical chain
     if (idx >= B * 2 * H) return;
     const int b = idx / (2 * H), j = idx % (2 * H);
     float v;
@@ -88,45 +89,56 @@ __global__ __launch_bounds__(256) void sum_to_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// One block: loss scalars from the (global) stats.
-__global__ __launch_bounds__(256) void latent_scalars_kernel(const float* __restrict__ stats,
-                                                             const float* __restrict__ hyper, float* scalars,
-                                                             int Z, int T) {
-    __shared__ float red[4];
+// Loss scalars from the (global) stats -- evaluated by EVERY block that needs them (Z-length reduction, a
+// few hundred cycles) so that scalars and latent gradients are one launch; block 0 writes the scalars out.
+struct LatentScalars {
+    float total, recon, kl, wkl, collapse, mi, mi_pen, cmi, Bg;
+};
+__device__ __forceinline__ LatentScalars latent_scalars_block(const float* __restrict__ stats,
+                                                              const float* __restrict__ hyper, int Z, int T,
+                                                              float* red /* [4] shared */) {
     const float Bg = stats[2 * Z + 2];
     float a = 0.f;
-    for (int j = threadIdx.x; j < Z; j += 256) {
+    for (int j = threadIdx.x; j < Z; j += blockDim.x) {
         const float mm = stats[j] / Bg, mv = stats[Z + j] / Bg;
         a += 1.0f + logf(mv) - mm * mm - mv;
     }
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float agg = -0.5f * ((red[0] + red[1]) + (red[2] + red[3]));
-        const float beta = hyper[0], lc = hyper[1], lmi = hyper[2], target = hyper[3];
-        const float mean_kl = stats[2 * Z] / Bg;
-        const float mi_raw = mean_kl - agg;
-        const float mi = mi_raw > 0.0f ? mi_raw : 0.0f;       // mx.maximum(mi, 0.0): grad iff mi_raw > 0
-        const float d = target - mi;
-        const bool gate = !(0.0f > d);                        // mx.maximum(0.0, d): grad to d iff 0 <= d
-        const float dpos = gate ? d : 0.0f;
-        const float collapse = lc * dpos, mi_pen = lmi * dpos;
-        const float kl = stats[2 * Z + 1] / Bg;
-        const float recon = stats[2 * Z + 3] / (Bg * (float)T);
-        const float wkl = beta * kl;
-        scalars[0] = recon + wkl + collapse + 0.0f + mi_pen;
-        scalars[1] = recon;
-        scalars[2] = kl;
-        scalars[3] = wkl;
-        scalars[4] = collapse;
-        scalars[5] = 0.0f;
-        scalars[6] = 0.0f;
-        scalars[7] = mi;
-        scalars[8] = mi_pen;
-        scalars[9] = (gate && mi_raw > 0.0f) ? -(lc + lmi) : 0.0f;
-        scalars[10] = Bg;
-    }
+    float tot = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+    LatentScalars r;
+    const float agg = -0.5f * tot;
+    const float beta = hyper[0], lc = hyper[1], lmi = hyper[2], target = hyper[3];
+    const float mean_kl = stats[2 * Z] / Bg;
+    const float mi_raw = mean_kl - agg;
+    r.mi = mi_raw > 0.0f ? mi_raw : 0.0f;              // mx.maximum(mi, 0.0): grad iff mi_raw > 0
+    const float d = target - r.mi;
+    const bool gate = !(0.0f > d);                     // mx.maximum(0.0, d): grad to d iff 0 <= d
+    const float dpos = gate ? d : 0.0f;
+    r.collapse = lc * dpos;
+    r.mi_pen = lmi * dpos;
+    r.kl = stats[2 * Z + 1] / Bg;
+    r.recon = stats[2 * Z + 3] / (Bg * (float)T);
+    r.wkl = beta * r.kl;
+    r.total = r.recon + r.wkl + r.collapse + 0.0f + r.mi_pen;
+    r.cmi = (gate && mi_raw > 0.0f) ? -(lc + lmi) : 0.0f;
+    r.Bg = Bg;
+    return r;
+}
+__device__ __forceinline__ void latent_scalars_write(const LatentScalars& r, float* scalars) {
+    scalars[0] = r.total; scalars[1] = r.recon; scalars[2] = r.kl; scalars[3] = r.wkl; scalars[4] = r.collapse;
+    scalars[5] = 0.0f; scalars[6] = 0.0f; scalars[7] = r.mi; scalars[8] = r.mi_pen; scalars[9] = r.cmi;
+    scalars[10] = r.Bg;
+}
+
+__global__ __launch_bounds__(256) void latent_scalars_kernel(const float* __restrict__ stats,
+                                                             const float* __restrict__ hyper, float* scalars,
+                                                             int Z, int T) {
+    __shared__ float red[4];
+    const LatentScalars r = latent_scalars_block(stats, hyper, Z, T, red);
+    if (threadIdx.x == 0) latent_scalars_write(r, scalars);
 }
 
 // d(total)/d(mu_raw), d(total)/d(lv_raw) for the local rows (z carries no gradient, Q2).
@@ -134,13 +146,16 @@ __global__ __launch_bounds__(256) void latent_grad_kernel(const float* __restric
                                                           const float* __restrict__ logvar,
                                                           const float* __restrict__ stats,
                                                           const float* __restrict__ hyper,
-                                                          const float* __restrict__ scalars, float* dmu_raw,
-                                                          float* dlv_raw, int B, int Z, float fb_min) {
+                                                          float* scalars, float* dmu_raw,
+                                                          float* dlv_raw, int B, int Z, int T, float fb_min) {
+    __shared__ float red[4];
+    const LatentScalars sc = latent_scalars_block(stats, hyper, Z, T, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) latent_scalars_write(sc, scalars);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * Z) return;
     const int j = idx % Z;
-    const float Bg = stats[2 * Z + 2];
-    const float beta = hyper[0], cmi = scalars[9];
+    const float Bg = sc.Bg;
+    const float beta = hyper[0], cmi = sc.cmi;
     const float m = mu[idx], lv = logvar[idx];
     // clip pass-through masks (mx.clip = minimum(maximum(x, lo), hi); never active inside the tanh bounds)
     const float pm = (m > -3.0f && m < 3.0f) ? 1.0f : 0.0f;
@@ -192,15 +207,15 @@ extern "C" int arcvae_enc_heads_forward(const float* hT, const float* cond, cons
         return ARCVAE_ERR_ARG;
     if (B <= 0 || H <= 0 || Z <= 0 || C < 0) return ARCVAE_ERR_ARG;
     const int H2 = 2 * H;
+    if (2 * Z + 4 > B * H2) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(build_comb_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, hT, cond, Wc, bc, comb,
-                       B, H, C);
+                       stats, 2 * Z + 4, B, H, C);
     int rc = arcvae_gemm_f32(0, 1, B, Z, H2, comb, H2, Wmu, H2, mu_raw, Z, bmu, 0, stream);
     if (rc) return rc;
     rc = arcvae_gemm_f32(0, 1, B, H2, H2, comb, H2, Wlh, H2, lh, H2, blh, ARCVAE_GEMM_TANH, stream);
     if (rc) return rc;
     rc = arcvae_gemm_f32(0, 1, B, Z, H2, lh, H2, Wlv, H2, lv_raw, Z, blv, 0, stream);
     if (rc) return rc;
-    if (arcvae_zero(stats, 1, 2 * Z + 4, 2 * Z + 4, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
     const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
     hipLaunchKernelGGL(latent_apply_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, mu_raw, lv_raw, eps, mu,
                        logvar, z, stats, B, Z, fb_min);
@@ -220,11 +235,12 @@ extern "C" int arcvae_latent_loss(const float* stats, const float* hyper, const 
                                   float* scalars, float* dmu_raw, float* dlv_raw, int B, int Z, int T,
                                   float free_bits, hipStream_t stream) {
     if (!stats || !hyper || !mu || !logvar || !scalars || B <= 0 || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
-    hipLaunchKernelGGL(latent_scalars_kernel, dim3(1), dim3(256), 0, stream, stats, hyper, scalars, Z, T);
     if (dmu_raw && dlv_raw) {
         const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
         hipLaunchKernelGGL(latent_grad_kernel, dim3(ceil_div(B * Z, 256)), dim3(256), 0, stream, mu, logvar, stats,
-                           hyper, scalars, dmu_raw, dlv_raw, B, Z, fb_min);
+                           hyper, scalars, dmu_raw, dlv_raw, B, Z, T, fb_min);
+    } else {
+        hipLaunchKernelGGL(latent_scalars_kernel, dim3(1), dim3(256), 0, stream, stats, hyper, scalars, Z, T);
     }
     return arcvae_launch_status();
 }
@@ -269,8 +285,9 @@ extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, co
     int rc;
     if (phase == 0 || phase == 1) {
         if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dmu_raw, Z, Wmu, H2, dcomb, H2, nullptr, 0, stream))) return rc;
-        if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dlv_raw, Z, Wlv, H2, dlh, H2, nullptr, 0, stream))) return rc;
-        hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, lh, dlh, (long)B * H2);
+        // dlh = (dlv_raw . Wlv) * (1 - lh^2): tanh backward fused into the GEMM epilogue
+        if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dlv_raw, Z, Wlv, H2, dlh, H2, lh, ARCVAE_GEMM_DTANH, stream)))
+            return rc;
         if ((rc = arcvae_gemm_f32(0, 0, B, H2, H2, dlh, H2, Wlh, H2, dcomb, H2, nullptr, ACC, stream))) return rc;
     }
     if (phase == 0 || phase == 2) {

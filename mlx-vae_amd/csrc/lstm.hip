@@ -219,11 +219,12 @@ inline bool hidden_ok(int H) { return H > 0 && (H % 64) == 0 && H <= 512; }
 //   hseq/cseq [L,T,B,H], gseq [L,T,B,4H] outputs (gseq = post-activation i,f,g,o)
 //   hseq_t [L,T,B*H] workspace: k-chunk-major copy of every h slab (operand layout of the step kernels)
 //   wt     [(2L-1),4H*H] workspace: k-chunk-major weight copies, refreshed here (weights change every step)
+//   wT_bwd optional [(2L-1),H*4H]: also write the BPTT layouts (then call the backward with retile = 0)
 //   hidden_dim: multiple of 64, <= 512.
 extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq,
-                                       float* hseq_t, float* cseq, float* gseq, float* wt, int B, int T, int V,
-                                       int H, int L, hipStream_t stream) {
+                                       float* hseq_t, float* cseq, float* gseq, float* wt, float* wT_bwd, int B,
+                                       int T, int V, int H, int L, hipStream_t stream) {
     if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !hseq_t || !cseq || !gseq || !wt) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || V <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
@@ -240,8 +241,17 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             src[n] = Wh[l]; dst[n] = wt + l * wsz; cols[n] = H; mode[n] = 0; ++n;
             if (l > 0) { src[n] = Wx[l]; dst[n] = wt + (L + l - 1) * wsz; cols[n] = H; mode[n] = 0; ++n; }
         }
-        const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
+        int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
+        if (wT_bwd) {  // the BPTT layouts too (same weights): keeps this launch off the chain between the sweeps
+            n = 0;
+            for (int l = 0; l < L; ++l) {
+                src[n] = Wh[l]; dst[n] = wT_bwd + l * wsz; cols[n] = H; mode[n] = 1; ++n;
+                if (l > 0) { src[n] = Wx[l]; dst[n] = wT_bwd + (L + l - 1) * wsz; cols[n] = H; mode[n] = 1; ++n; }
+            }
+            rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
+            if (rc != ARCVAE_OK) return rc;
+        }
     }
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
@@ -274,13 +284,13 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
 // (models/encoder.py:106).  Produces dG [L,T,B,4H] (pre-activation gate gradients); weight
 // gradients are formed from dG by arcvae_enc_lstm_wgrad.
 //   dcs, dxs  workspaces [L,T,B,H];  dG_t workspace [L,T,B*4H] (k-chunk-major copy of dG);  wT workspace
-//   [(2L-1),H*4H] (k-chunk-major Wh_l^T, Wx_l^T copies, refreshed when s_begin == 0).  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
+//   [(2L-1),H*4H] (k-chunk-major Wh_l^T, Wx_l^T copies, refreshed when s_begin == 0 and retile != 0).  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
 //   Schedule: cell(l,t) at launch (T-1-t) + 2(L-1-l); xproj_l(t) (dX_l[t] = dG^{l+1}_t . Wx_{l+1}) one launch earlier.
 //   After launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).
 extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                         float* dG_t, float* dcs, float* dxs, float* wT, int B, int T, int H,
-                                        int L, int s_begin, int s_end, hipStream_t stream) {
+                                        int L, int s_begin, int s_end, int retile, hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
@@ -290,7 +300,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     const long lH = (long)T * sH, lG = (long)T * sG;
     const long wsz = (long)H * 4 * H;
     // tiled transposed weight copies: WhT[l] at wT + l*wsz, WxT[l] (l>=1) at wT + (L + l - 1)*wsz
-    if (s_begin == 0) {
+    if (s_begin == 0 && retile) {
         const float* src[16];
         float* dst[16];
         int cols[16], mode[16];
@@ -351,11 +361,12 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   l >= 1: dWx_l += dG_l[t]^T . hseq_{l-1}[t];  all l: dWh_l += dG_l[t]^T . hseq_l[t-1] (t >= 1);  dbias_l += colsum
 //   l == 0: dTable0[v] += sum_{(t,b): x=v} dG_0[t,b]   (dtable_ws [V,4H], zeroed when `first` != 0)
 //   when `last` != 0 (all ranges done): dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;  dbias_0 += colsum(dTable0)
+//   parts: bit 0 = the per-layer GEMMs, bit 1 = the layer-0 token-table path (they are independent: two streams)
 extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0,
                                      const float* hseq, const float* dG, float* dtable_ws, float* dEmb,
                                      float* const* dWx, float* const* dWh, float* const* dbias, int B, int T,
                                      int V, int E, int H, int L, int t_lo, int t_hi, int first, int last,
-                                     hipStream_t stream) {
+                                     int parts, hipStream_t stream) {
     if (!x_tb || !emb || !Wx0 || !hseq || !dG || !dtable_ws || !dEmb || !dWx || !dWh || !dbias)
         return ARCVAE_ERR_ARG;
     if (t_lo < 0 || t_hi > T || t_lo > t_hi) return ARCVAE_ERR_ARG;
@@ -363,10 +374,11 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     const long lH = (long)TB * H, lG = (long)TB * G;
     const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK;
     int rc;
-    if (first && arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+    const bool do_layers = (parts & 1) != 0, do_table = (parts & 2) != 0;
+    if (do_table && first && arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
     if (t_hi > t_lo) {
         const int nt = t_hi - t_lo;
-        for (int l = 0; l < L; ++l) {
+        for (int l = 0; do_layers && l < L; ++l) {
             const float* dGl = dG + l * lG;
             const int t1 = t_lo > 1 ? t_lo : 1;  // dWh pairs dG[t] with h[t-1]
             if (t_hi > t1) {
@@ -382,11 +394,15 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                 if (rc) return rc;
             }
         }
-        rc = arcvae_segsum_rows_accum(dG + (long)t_lo * B * G, x_tb + (long)t_lo * B, nt * B, V, G, dtable_ws, stream);
-        if (rc) return rc;
+        if (do_table) {
+            rc = arcvae_segsum_rows_accum(dG + (long)t_lo * B * G, x_tb + (long)t_lo * B, nt * B, V, G, dtable_ws,
+                                          stream);
+            if (rc) return rc;
+        }
     }
-    if (last) {
-        rc = arcvae_gemm_f32(0, 0, V, E, G, dtable_ws, G, Wx0, E, dEmb, E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
+    if (last && do_table) {
+        rc = arcvae_gemm_f32(0, 0, V, E, G, dtable_ws, G, Wx0, E, dEmb, E, nullptr,
+                             ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_NO_SKINNY, stream);
         if (rc) return rc;
         rc = arcvae_gemm_f32(1, 0, G, E, V, dtable_ws, G, emb, E, dWx[0], E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
         if (rc) return rc;

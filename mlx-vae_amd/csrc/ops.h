@@ -10,6 +10,7 @@
 #define ARCVAE_GEMM_NO_SKINNY 8
 #define ARCVAE_GEMM_TILE64 16   /* force 64x64 tiles (tuning / tests) */
 #define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
+#define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */
 
 extern "C" {
 int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
