@@ -260,3 +260,40 @@ def test_train_cli_smoke(tmp_path):
     assert (tmp_path / "ck" / "training_history.json").exists()
     with pytest.raises(FileNotFoundError):
         train.main(["--synthetic", "48", "--resume", "--checkpoint_dir", str(tmp_path / "none"), "--no_progress"])
+
+
+def test_parameter_tree_names_and_state_dict_round_trip():
+    """Parameter-tree names of SURVEY section 8b (MLX nn.LSTM: Wx, Wh, bias; Linear: weight, bias)."""
+    cfg = TINY
+    vae = _vae(cfg, O.init_params(cfg, 7))
+    pe, pd = vae.encoder.parameters(), vae.decoder.parameters()
+    assert set(pe) == {"embedding", "lstm_layer_0", "lstm_layer_1", "condition_fc", "fc_mu", "fc_logvar_hidden", "fc_logvar"}
+    assert set(pe["lstm_layer_0"]) == {"Wx", "Wh", "bias"} and tuple(pe["lstm_layer_0"]["Wx"].shape) == (4 * cfg.H, cfg.E)
+    assert set(pd) == {"z_to_hidden", "condition_to_hidden", "embedding", "lstm_layer_0", "lstm_layer_1", "fc_out"}
+    assert tuple(pd["lstm_layer_0"]["Wx"].shape) == (4 * cfg.H, cfg.E + cfg.C)
+    assert tuple(vae.encoder.fc_logvar.bias.shape) == (cfg.Z,)
+    from models.vae import ARCVAE
+    fresh = ARCVAE(vocab_size=cfg.V, embedding_dim=cfg.E, hidden_dim=cfg.H, latent_dim=cfg.Z, num_conditions=cfg.C,
+                   num_layers=cfg.L)
+    assert torch.allclose(fresh.encoder.fc_logvar.bias, torch.full((cfg.Z,), 0.35, device="cuda"))  # encoder.py:71-74
+    k = 1.0 / np.sqrt(cfg.H)
+    assert float(fresh.encoder.lstm_layer_0.Wh.abs().max()) <= k + 1e-6                               # M1 init range
+    fresh.encoder.load_state_dict(vae.encoder.state_dict())
+    assert torch.equal(fresh.encoder.store.flat, vae.encoder.store.flat)
+    hid, cell = vae.decoder.initialize_hidden_state(torch.zeros(3, cfg.Z), np.zeros((3, cfg.C), np.float32))
+    assert tuple(hid.shape) == (cfg.L, 3, cfg.H) and float(cell.abs().max()) == 0.0
+    ref = (vae.decoder.store.p("z_to_hidden.bias") + vae.decoder.store.p("condition_to_hidden.bias")) / 2
+    assert torch.allclose(hid[0, 0], ref, atol=1e-6)
+
+
+def test_train_cli_resume(tmp_path):
+    import train
+    ck = str(tmp_path / "ck")
+    common = ["--synthetic", "40", "--batch_size", "16", "--hidden_dim", "64", "--embedding_dim", "16", "--latent_dim", "8",
+              "--checkpoint_dir", ck, "--no_progress"]
+    train.main(common + ["--epochs", "1"])
+    h1 = json.load(open(os.path.join(ck, "training_history.json")))
+    assert h1["epoch"] == [0] and len(h1["train_loss"]) == 1
+    train.main(common + ["--epochs", "2", "--resume"])       # resumes at epoch 1 from checkpoint_best.npz
+    h2 = json.load(open(os.path.join(ck, "training_history.json")))
+    assert h2["epoch"] == [0, 1] and h2["beta"][1] == pytest.approx(0.05 / 20)
