@@ -95,8 +95,11 @@ class EngineOps:
         self.comm = torch.cuda.Stream(device=engine.device)
 
     def forward_local(self) -> None:
+        # same host order as the single-process step: decoder segments first (they only follow the input copies),
+        # then the encoder forward, so the decoder overlaps the forward sweep
+        self.eng.side.wait_stream(torch.cuda.current_stream())
+        self.eng.enqueue_decoder(self.ws, self.global_rows, self.run, wait_current=False)
         self.eng.enqueue_encoder_forward(self.ws, self.run)
-        self.eng.enqueue_decoder(self.ws, self.global_rows, self.run)
 
     def backward_local(self) -> None:
         self.eng.enqueue_backward(self.ws, self.run)

@@ -102,7 +102,8 @@ struct TileLoader {
 };
 
 template <int BM, int BN, bool AK, bool BKC, int VA, int VB>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_tile_body(const GemmP& p, const int bx, const int by, const int bz,
+                                               const bool split) {
     constexpr int WM = BM / 2, WN = BN / 2;   // wave tile (2x2 waves)
     constexpr int MT = WM / 32, NT = WN / 32;  // 32x32 MFMA tiles per wave
     constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
     f32x16 acc[MT][NT];
@@ -162,14 +163,13 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
         __syncthreads();
     }
 
-    const bool split = gridDim.z > 1;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = n0 + wn * WN + j * 32 + (lane & 31);
             if (col >= p.N) continue;
-            const float bv = (p.bias && p.act != 2 && blockIdx.z == 0) ? p.bias[col] : 0.f;
+            const float bv = (p.bias && p.act != 2 && bz == 0) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -186,6 +186,28 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
                 }
             }
         }
+}
+
+template <int BM, int BN, bool AK, bool BKC, int VA, int VB>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
+    gemm_tile_body<BM, BN, AK, BKC, VA, VB>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z > 1);
+}
+
+// Grouped launch: up to 8 same-layout problems in ONE launch (blockIdx.z walks [problem][k-slice]); used for the
+// per-layer weight-gradient GEMMs of a BPTT chunk, which are small, independent and otherwise each pay a launch.
+#define ARCVAE_GEMM_GROUP_MAX 8
+struct GemmGroup {
+    GemmP p[ARCVAE_GEMM_GROUP_MAX];
+    int zoff[ARCVAE_GEMM_GROUP_MAX + 1];
+    int n;
+};
+template <int BM, int BN, bool AK, bool BKC, int VA, int VB>
+__global__ __launch_bounds__(256) void gemm_tile_group_kernel(GemmGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.z >= g.zoff[i + 1]) ++i;
+    const GemmP& p = g.p[i];
+    if ((int)blockIdx.y * BM >= p.M || (int)blockIdx.x * BN >= p.N) return;
+    gemm_tile_body<BM, BN, AK, BKC, VA, VB>(p, blockIdx.x, blockIdx.y, blockIdx.z - g.zoff[i], true);
 }
 
 // Skinny: 16x16 tile per block; A [M,K] K-contiguous; B either [N,K] (BKC) or [K,N].
@@ -294,5 +316,45 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     }
     if (big) launch_tile_t<128, 128>(p, grid, ak, bk, va4, vb4, stream);
     else launch_tile_t<64, 64>(p, grid, ak, bk, va4, vb4, stream);
+    return arcvae_launch_status();
+}
+
+// C_i[M,N] += A_i^T . B_i for i < n, one launch: A_i stored [K_i, M] (lda), B_i stored [K_i, N] (ldb), all f32
+// atomics (split-K inside each problem).  Internal (ops.h); falls back to n single launches when the operands do
+// not allow the 16-byte path.
+int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
+                               const float* const* B, int ldb, float* const* C, int ldc, hipStream_t stream) {
+    if (n <= 0 || n > ARCVAE_GEMM_GROUP_MAX || M <= 0 || N <= 0) return ARCVAE_ERR_ARG;
+    bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0;
+    for (int i = 0; i < n; ++i) vec = vec && aligned16(A[i]) && aligned16(B[i]) && K[i] > 0;
+    if (!vec) {
+        for (int i = 0; i < n; ++i) {
+            if (K[i] <= 0) continue;
+            const int rc = arcvae_gemm_f32(1, 0, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr,
+                                           ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK, stream);
+            if (rc) return rc;
+        }
+        return ARCVAE_OK;
+    }
+    GemmGroup g;
+    g.n = n;
+    const int tiles = ceil_div(M, 64) * ceil_div(N, 64);
+    int ztot = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmP& p = g.p[i];
+        p.A = A[i]; p.B = B[i]; p.C = C[i]; p.bias = nullptr;
+        p.M = M; p.N = N; p.K = K[i]; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+        p.accumulate = 1; p.act = 0;
+        int z = min(ceil_div(512, tiles * n), max(1, K[i] / 128));
+        z = max(1, z);
+        p.kchunk = ceil_div(ceil_div(K[i], z), BK) * BK;
+        z = ceil_div(K[i], p.kchunk);
+        g.zoff[i] = ztot;
+        ztot += z;
+    }
+    g.zoff[n] = ztot;
+    for (int i = n; i < ARCVAE_GEMM_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.zoff[i + 1] = ztot; }
+    dim3 grid(ceil_div(N, 64), ceil_div(M, 64), ztot);
+    hipLaunchKernelGGL((gemm_tile_group_kernel<64, 64, false, false, 4, 4>), grid, dim3(256), 0, stream, g);
     return arcvae_launch_status();
 }

@@ -372,25 +372,36 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     if (t_lo < 0 || t_hi > T || t_lo > t_hi) return ARCVAE_ERR_ARG;
     const int G = 4 * H, TB = T * B;
     const long lH = (long)TB * H, lG = (long)TB * G;
-    const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK;
     int rc;
     const bool do_layers = (parts & 1) != 0, do_table = (parts & 2) != 0;
     if (do_table && first && arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
     if (t_hi > t_lo) {
         const int nt = t_hi - t_lo;
-        for (int l = 0; do_layers && l < L; ++l) {
-            const float* dGl = dG + l * lG;
+        if (do_layers) {  // all per-layer weight-gradient GEMMs of this time range in ONE grouped launch
+            const float* Ag[2 * ARCVAE_MAX_LAYERS];
+            const float* Bg[2 * ARCVAE_MAX_LAYERS];
+            float* Cg[2 * ARCVAE_MAX_LAYERS];
+            int Kg[2 * ARCVAE_MAX_LAYERS];
+            int n = 0;
             const int t1 = t_lo > 1 ? t_lo : 1;  // dWh pairs dG[t] with h[t-1]
-            if (t_hi > t1) {
-                rc = arcvae_gemm_f32(1, 0, G, H, (t_hi - t1) * B, dGl + (long)t1 * B * G, G,
-                                     hseq + l * lH + (long)(t1 - 1) * B * H, H, dWh[l], H, nullptr, SK, stream);
+            for (int l = 0; l < L; ++l) {
+                const float* dGl = dG + l * lG;
+                if (t_hi > t1) {
+                    Ag[n] = dGl + (long)t1 * B * G; Bg[n] = hseq + l * lH + (long)(t1 - 1) * B * H;
+                    Cg[n] = dWh[l]; Kg[n] = (t_hi - t1) * B; ++n;
+                }
+                if (l > 0) {
+                    Ag[n] = dGl + (long)t_lo * B * G; Bg[n] = hseq + (l - 1) * lH + (long)t_lo * B * H;
+                    Cg[n] = dWx[l]; Kg[n] = nt * B; ++n;
+                }
+            }
+            for (int i = 0; i < n; i += 8) {
+                rc = arcvae_gemm_tn_group_accum(n - i < 8 ? n - i : 8, G, H, Kg + i, Ag + i, G, Bg + i, H, Cg + i, H,
+                                                stream);
                 if (rc) return rc;
             }
-            if (l > 0) {
-                rc = arcvae_gemm_f32(1, 0, G, H, nt * B, dGl + (long)t_lo * B * G, G,
-                                     hseq + (l - 1) * lH + (long)t_lo * B * H, H, dWx[l], H, nullptr, SK, stream);
-                if (rc) return rc;
-                rc = arcvae_colsum_accum(dGl + (long)t_lo * B * G, nt * B, G, G, dbias[l], 1.0f, stream);
+            for (int l = 1; l < L; ++l) {
+                rc = arcvae_colsum_accum(dG + l * lG + (long)t_lo * B * G, nt * B, G, G, dbias[l], 1.0f, stream);
                 if (rc) return rc;
             }
         }

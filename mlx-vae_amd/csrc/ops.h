@@ -12,6 +12,10 @@
 #define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
 #define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */
 
+// internal (C++ linkage): grouped weight-gradient GEMMs, see gemm.hip
+int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
+                               const float* const* B, int ldb, float* const* C, int ldc, hipStream_t stream);
+
 extern "C" {
 int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, const float* bias, int flags,
