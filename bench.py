@@ -111,6 +111,8 @@ def main():
                     help="launch mode: one multi-stream hipGraph, eager launches, or per-stream graph segments")
     ap.add_argument("--cpu-steps", type=int, default=6, help="oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the dominant-kernel probe (for `rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only`)")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel driver (process group + collectives) even at world size 1")
     args = ap.parse_args()
@@ -185,6 +187,11 @@ def main():
         else:
             dp.step()
 
+    if args.roofline_only:
+        one_step(0)
+        torch.cuda.synchronize()
+        print(json.dumps({"roofline": roofline_probe(eng, ws, torch)}), flush=True)
+        return
     log(f"rank {rank}/{world}: warm-up ({args.warmup} steps, mode={mode})")
     for i in range(args.warmup):
         one_step(i)
