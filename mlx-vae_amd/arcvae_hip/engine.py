@@ -460,8 +460,11 @@ class StepEngine:
                 self._enc_fwd(ws, True)
             latent_loss(ws, self.d, fb, True)
 
+        # the tail chunk's token-table half goes to the SIDE stream: the decoder finished long ago and, unlike a
+        # fourth stream, `side` owns a hardware queue of its own (HIP maps streams onto 4 queues), so the two
+        # halves really run side by side
         encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue, after_first=after_first,
-                         aux2=self.aux2)
+                         aux2=self.side)
 
     def enqueue_recon(self, ws: Workspace, run=_inline) -> None:
         """stats[2Z+3] = sum of this process's CE row sums (after the decoder's TF walk)."""
