@@ -15,8 +15,8 @@
  *   - `const float* const*` arguments are HOST arrays of device pointers (one per LSTM layer);
  *   - gradients are accumulated ("+="): zero the flat gradient buffer once per step;
  *   - float32 arithmetic throughout (the reference's dtype), contractions on the exact-f32
- *     MFMA forms; hidden_dim must be a multiple of 64, num_layers <= 8, num_conditions <= 8,
- *     vocab_size <= 127.
+ *     MFMA forms; hidden_dim a multiple of 64 and <= 512, num_layers <= 8, 1 <= num_conditions <= 8,
+ *     vocab_size <= 127 (anything else is ARCVAE_ERR_ARG, never a silent fallback).
  */
 #ifndef ARCVAE_HIP_H
 #define ARCVAE_HIP_H

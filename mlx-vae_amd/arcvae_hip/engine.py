@@ -352,12 +352,9 @@ class StepEngine:
         self._ws: Dict[Tuple[int, int, bool], Workspace] = {}
         self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
         self._runners: Dict[Tuple, SegmentRunner] = {}
-        # the critical chain runs on the caller's stream; decoder and weight-gradient GEMMs on LOWER-priority
-        # streams so their blocks are dispatched behind the latency-bound step kernels
-        lo = int(os.environ.get("ARCVAE_SIDE_PRIORITY", "0"))
-        self.side = torch.cuda.Stream(device=self.device, priority=lo)
-        self.aux = torch.cuda.Stream(device=self.device, priority=lo)
-        self.aux2 = torch.cuda.Stream(device=self.device, priority=lo)
+        # the critical chain runs on the caller's stream (stream priorities made no measurable difference)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.aux = torch.cuda.Stream(device=self.device)
         self.hyper_host = dict(beta=0.4, lambda_collapse=0.01, lambda_mi=0.0, target_mi=4.85, free_bits=0.5)
         self.mode = "segments"
         self.ev_chain = torch.cuda.Event()
@@ -491,17 +488,13 @@ class StepEngine:
         run(("finish" if update else "finish_noupdate") + ("_r" if with_recon else ""), fin, main)
 
     def _enqueue_step(self, ws: Workspace, lr: float, global_rows: int, update: bool, run=_inline) -> None:
-        """Single-process step.  Host enqueue order = GPU priority: encoder forward first (the critical chain),
-        then the decoder (it overlaps the forward sweep, whose launches leave CUs idle at every seam), then the
-        fused loss + dcomb + BPTT segments with the weight-gradient chunks on aux; the decoder is only joined at
-        the very end (nothing on the encoder's backward path needs the reconstruction term)."""
+        """Single-process step.  Host enqueue order: the decoder segment (one short graph launch; it overlaps the
+        forward sweep, whose launches leave CUs idle at every seam), the encoder forward, then the fused loss +
+        dcomb + BPTT segments with the weight-gradient chunks on aux; the decoder is only joined at the very end
+        (nothing on the encoder's backward path needs the reconstruction term)."""
         self.side.wait_stream(torch.cuda.current_stream())   # the decoder only has to follow the input copies
-        if os.environ.get("ARCVAE_DECODER_FIRST", "1") == "1":
-            self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)
-            self.enqueue_encoder_forward(ws, run)
-        else:
-            self.enqueue_encoder_forward(ws, run)
-            self.enqueue_decoder(ws, global_rows, run, wait_current=False)
+        self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)
+        self.enqueue_encoder_forward(ws, run)
         self.enqueue_backward(ws, run)
         self.enqueue_finish(ws, lr, update, run, with_recon=True)
 
