@@ -215,6 +215,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     scal = ws.scalars.cpu().numpy()
+    eng.check_gates()  # a device-side gate that gave up waiting would mean the streams lost their order
 
     if rank == 0:
         ms = 1e3 * dt / args.steps

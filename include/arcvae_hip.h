@@ -167,6 +167,18 @@ int arcvae_transpose_batched(const float* const* src, float* const* dst, const i
                              int n, arcvae_stream_t stream);
 int arcvae_scale_inplace(float* x, long n, float s, arcvae_stream_t stream);
 int arcvae_zero(float* x, int rows, int cols, int ld, arcvae_stream_t stream);
+/* Device-side gates (no reference counterpart): cross-stream ordering by a one-wave polling kernel instead of an
+ * event wait, because a hardware queue blocked on an event slows every dependent dispatch of the chain that is
+ * running.  wait: returns once (int)(*flag - ((*steps) * stride + offset)) >= 0 (steps may be
+ * NULL: target = offset); advance != 0: ++*steps afterwards; bounded spin of max_polls polls (~1 us each), on expiry
+ * *err += 1.  set: *flag = value (add == 0) or *flag += value, ordered after the earlier work of the stream. */
+int arcvae_gate_wait(const unsigned* flag, unsigned* steps, unsigned stride, unsigned offset, int advance,
+                     unsigned max_polls, unsigned* err, arcvae_stream_t stream);
+int arcvae_gate_set(unsigned* flag, unsigned value, int add, arcvae_stream_t stream);
+/* Diagnostic (tools/step_trace.py; no reference counterpart): device-side {start,end} stamps, 100 MHz ticks, of the
+ * LSTM step launches recorded after this call.  buf: 2*cap u64 (forward launch s -> slot s, BPTT launch s -> slot
+ * cap/2 + s); buf = NULL switches tracing off (default). */
+int arcvae_set_step_trace(unsigned long long* buf, int cap);
 int arcvae_tile_weights(const float* const* src, float* const* dst, const int* cols, const int* mode, int n, int H,
                         arcvae_stream_t stream);
 

@@ -190,6 +190,60 @@ def _inline(key, fn, stream) -> None:
         fn()
 
 
+class Gates:
+    """Device-side cross-stream ordering for the single-process step (csrc/misc.hip: gate_wait/gate_set).
+
+    Why not events: a stream waiting on another stream's event parks a barrier packet at the head of its hardware
+    queue, and on MI355X every such blocked queue adds ~1 us to EACH dependent dispatch of the running LSTM chain
+    (tools/step_trace.py: 4.72 -> 5.68 us per launch; the host runs steps ahead, so `side` and `aux` were blocked
+    almost all the time).  With gates the waiting stream runs a one-wave polling kernel instead.
+
+    Words (one 128-B line each):  P main's signal count (exactly STRIDE per step), Q aux's (1 per step),
+    NS / NA steps finished by side / aux (the waiter's own ticket counter), ERR expired gates, PROBE self-test.
+    """
+    STRIDE = 8
+    LONG, SHORT = 4_000_000, 3_000     # polls (~1 us each): ~4 s before a gate gives up; ~3 ms for the probe
+    P, Q, NS, NA, ERR, PROBE = range(6)
+
+    def __init__(self, device):
+        self.mem = torch.zeros(6 * 32, dtype=torch.int32, device=device)
+        self._probed: Dict[Tuple[int, int], bool] = {}
+
+    def word(self, i: int) -> C.c_void_p:
+        return C.c_void_p(self.mem.data_ptr() + 128 * i)
+
+    def signal(self, w: int, add: int = 1) -> None:
+        call("arcvae_gate_set", self.word(w), add, 1, stream_ptr())
+
+    def wait(self, w: int, steps: int, stride: int, offset: int, advance: bool = False) -> None:
+        call("arcvae_gate_wait", self.word(w), self.word(steps), stride, offset, int(advance), self.LONG,
+             self.word(self.ERR), stream_ptr())
+
+    def errors(self) -> int:
+        return int(self.mem[self.ERR * 32].item())
+
+    def probe(self, waiter: torch.cuda.Stream, signaller: torch.cuda.Stream) -> bool:
+        """True iff a gate on `waiter` can be released from `signaller`, i.e. the two streams do NOT share a
+        hardware queue (HIP multiplexes streams onto a few queues; on a shared one the gate would sit in front of
+        its own release).  Costs a few ms once per stream pair."""
+        key = (waiter.cuda_stream, signaller.cuda_stream)
+        if key not in self._probed:
+            torch.cuda.synchronize()
+            self.mem[self.PROBE * 32] = 0
+            before = self.errors()
+            with torch.cuda.stream(waiter):
+                call("arcvae_gate_wait", self.word(self.PROBE), C.c_void_p(0), 0, 1, 0, self.SHORT,
+                     self.word(self.ERR), stream_ptr())
+            with torch.cuda.stream(signaller):
+                call("arcvae_gate_set", self.word(self.PROBE), 1, 0, stream_ptr())
+            torch.cuda.synchronize()
+            ok = self.errors() == before
+            self.mem[self.ERR * 32] = before
+            torch.cuda.synchronize()
+            self._probed[key] = ok
+        return self._probed[key]
+
+
 class SegmentRunner:
     """Runs named launch sequences on given streams -- eagerly, or captured ONCE each as a single-stream
     hipGraph and replayed.  Single-stream (linear) segments with eager events between them are used instead
@@ -278,7 +332,8 @@ class EncoderBackwardPlan:
 
 
 def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
-                     run=_inline, prologue=None, after_first=None, aux2: Optional[torch.cuda.Stream] = None) -> None:
+                     run=_inline, prologue=None, after_first=None, aux2: Optional[torch.cuda.Stream] = None,
+                     gates: Optional[Gates] = None) -> None:
     """Backward of heads + LSTM stack on (current stream, aux).  `prologue` (optional) is enqueued at the head
     of the first main-stream segment (used to fuse encoder forward + loss into it); `after_first` (optional) is
     called on the host right after that first segment has been enqueued (the decoder is enqueued there: early
@@ -296,6 +351,9 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
         run("enc_all", everything, main)
         if after_first:
             after_first()
+        return
+    if gates is not None:
+        _encoder_backward_gated(plan, ws, aux, aux2, run, prologue, after_first, gates)
         return
     for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
         def main_seg(c=c, s0=s0, s1=s1):
@@ -322,6 +380,52 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
             aux2.wait_stream(aux)  # the token table accumulates across chunks: follow the earlier chunks
             aux2.wait_event(ev)
             run(f"aux2_{c}", lambda a=t_lo, b=t_hi, f=first, l=last: plan.wgrad(a, b, f, l, 2), aux2)
+        run(f"aux{c}", aux_seg, aux)
+    main.wait_stream(aux)
+    if aux2 is not None:
+        main.wait_stream(aux2)
+
+
+def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2, run, prologue, after_first,
+                            g: Gates) -> None:
+    """encoder_backward with device-side gates instead of event waits (class Gates).  Main's signals of a step:
+    #1 inputs ready (enqueued by the caller), #(2+c) after sweep chunk c, the last chunk topping P up to a multiple
+    of STRIDE.  aux: chunk c runs behind signal #(2+c); it signals Q once (after its last-but-one chunk).  side:
+    the tail chunk's token-table half runs behind Q (the table accumulates across aux's earlier chunks) and the last
+    signal.  The current stream joins aux (and the caller joins side) with ordinary events at the very end, when the
+    chain is over."""
+    main = torch.cuda.current_stream()
+    nc = len(plan.chunks)
+    if nc + 1 > g.STRIDE:
+        raise ValueError("too many BPTT chunks for the gate stride")
+    tail_on_side = aux2 is not None and nc >= 2
+    for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
+        def main_seg(c=c, s0=s0, s1=s1, last=last):
+            if c == 0:
+                if prologue:
+                    prologue()
+                plan.heads(1)
+            plan.sweep(s0, s1)
+            g.signal(g.P, g.STRIDE - (1 + c) if last else 1)
+
+        def aux_seg(c=c, t_lo=t_lo, t_hi=t_hi, first=first, last=last):
+            g.wait(g.P, g.NA, g.STRIDE, g.STRIDE if last else 2 + c, advance=last)
+            if c == 0:
+                plan.heads(2)
+            plan.wgrad(t_lo, t_hi, first, last, 1 if (last and tail_on_side) else 3)
+            if c == max(nc - 2, 0):
+                g.signal(g.Q, 1)
+
+        def side_seg(t_lo=t_lo, t_hi=t_hi, first=first, last=last):
+            g.wait(g.Q, g.NS, 1, 1)
+            g.wait(g.P, g.NS, g.STRIDE, g.STRIDE, advance=True)
+            plan.wgrad(t_lo, t_hi, first, last, 2)
+
+        run(f"main{c}", main_seg, main)
+        if c == 0 and after_first:
+            after_first()
+        if last and tail_on_side:
+            run(f"aux2_{c}", side_seg, aux2)
         run(f"aux{c}", aux_seg, aux)
     main.wait_stream(aux)
     if aux2 is not None:
@@ -360,6 +464,9 @@ class StepEngine:
         self.ev_chain = torch.cuda.Event()
         self.ev_dec_bwd = torch.cuda.Event()
         self.ev_enc_fwd = torch.cuda.Event()
+        # device-side gates instead of event waits in the single-process step (class Gates); ARCVAE_GATES=0: events
+        self.gates: Optional[Gates] = Gates(self.device) if os.environ.get("ARCVAE_GATES", "1") != "0" else None
+        self._gating: Dict[int, bool] = {}
 
     # `use_graph` is the older boolean switch: True -> captured segments, False -> eager launches
     @property
@@ -369,6 +476,33 @@ class StepEngine:
     @use_graph.setter
     def use_graph(self, v: bool) -> None:
         self.mode = "segments" if v else "eager"
+
+    def _gating_ok(self, main: torch.cuda.Stream) -> bool:
+        """Gates need main, side and aux on three different hardware queues: probe once per main stream, replacing
+        side / aux by other pool streams until the probe passes; otherwise keep the event waits."""
+        if self.gates is None:
+            return False
+        key = main.cuda_stream
+        if key not in self._gating:
+            g, ok = self.gates, False
+            for _ in range(8):
+                if not g.probe(self.side, main):
+                    self.side = torch.cuda.Stream(device=self.device)
+                    continue
+                if not (g.probe(self.aux, main) and g.probe(self.side, self.aux) and g.probe(self.aux, self.side)):
+                    self.aux = torch.cuda.Stream(device=self.device)
+                    continue
+                ok = True
+                break
+            if not ok:
+                print("[arcvae_hip] no three streams on distinct hardware queues found: keeping event waits")
+            self._gating = {key: ok}  # side/aux may have changed: other main streams are re-probed
+        return self._gating[key]
+
+    def check_gates(self) -> None:
+        """Raise if a gate ever gave up waiting (results after that point are not ordered).  Host sync."""
+        if self.gates is not None and self.gates.errors() != 0:
+            raise _lib.ArcvaeHipError("a device-side gate expired (stream ordering was lost); set ARCVAE_GATES=0")
 
     # ---- buffers ----------------------------------------------------------------------------
     def workspace(self, B: int, T: int, train: bool = True) -> Workspace:
@@ -409,7 +543,7 @@ class StepEngine:
 
     # ---- the phases of a step (data-parallel collectives go between them, dp.py) ------------------------
     def enqueue_decoder(self, ws: Workspace, global_rows: int, run=_inline, backward: bool = True,
-                        wait_current: bool = True, split_events: bool = True) -> None:
+                        wait_current: bool = True, split_events: bool = True, gate=None) -> None:
         """Dense decoder on the side stream: forward + TF walk + CE row sums (ev_chain), then its whole backward
         (ev_dec_bwd).  Independent of the encoder (Q2); it only has to follow the input copies."""
         d = self.d
@@ -417,6 +551,8 @@ class StepEngine:
             self.side.wait_stream(torch.cuda.current_stream())
 
         def dec_fwd():
+            if gate is not None:  # (gates, advance): wait for main's "inputs ready" signal of this step
+                gate[0].wait(Gates.P, Gates.NS, Gates.STRIDE, 1, advance=gate[1])
             if backward:
                 self.dec.grad.zero_()
             decoder_forward_dense(self.dec, ws, d)
@@ -447,7 +583,8 @@ class StepEngine:
         run("enc_fwd", lambda: self._enc_fwd(ws, backward), torch.cuda.current_stream())
         self.ev_enc_fwd.record(torch.cuda.current_stream())
 
-    def enqueue_backward(self, ws: Workspace, run=_inline, fuse_forward: bool = False, after_first=None) -> None:
+    def enqueue_backward(self, ws: Workspace, run=_inline, fuse_forward: bool = False, after_first=None,
+                         gates: Optional[Gates] = None) -> None:
         """`stats[:2Z+3]` holds GLOBAL sums (or, with fuse_forward, will: single process): latent loss scalars
         and gradients, then the encoder backward.  Does NOT wait for the decoder."""
         fb = float(self.hyper_host["free_bits"])
@@ -461,7 +598,7 @@ class StepEngine:
         # fourth stream, `side` owns a hardware queue of its own (HIP maps streams onto 4 queues), so the two
         # halves really run side by side
         encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue, after_first=after_first,
-                         aux2=self.side)
+                         aux2=self.side, gates=gates)
 
     def enqueue_recon(self, ws: Workspace, run=_inline) -> None:
         """stats[2Z+3] = sum of this process's CE row sums (after the decoder's TF walk)."""
@@ -492,7 +629,21 @@ class StepEngine:
         forward sweep, whose launches leave CUs idle at every seam), the encoder forward, then the fused loss +
         dcomb + BPTT segments with the weight-gradient chunks on aux; the decoder is only joined at the very end
         (nothing on the encoder's backward path needs the reconstruction term)."""
-        self.side.wait_stream(torch.cuda.current_stream())   # the decoder only has to follow the input copies
+        main = torch.cuda.current_stream()
+        if self.mode != "graph" and self._gating_ok(main):
+            g = self.gates
+            nc = len(EncoderBackwardPlan(self.enc, ws, self.d).chunks)
+
+            def grun(key, fn, stream, _run=run):             # gated segments are recorded under their own names
+                _run(f"gated:{key}", fn, stream)
+
+            g.signal(g.P, 1)                                 # signal #1: the input copies are done (plain launch)
+            self.enqueue_decoder(ws, global_rows, grun, wait_current=False, split_events=False, gate=(g, nc < 2))
+            self.enqueue_encoder_forward(ws, run)
+            self.enqueue_backward(ws, grun, gates=g)
+            self.enqueue_finish(ws, lr, update, run, with_recon=True)
+            return
+        self.side.wait_stream(main)                          # the decoder only has to follow the input copies
         self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)
         self.enqueue_encoder_forward(ws, run)
         self.enqueue_backward(ws, run)

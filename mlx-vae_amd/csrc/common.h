@@ -21,6 +21,42 @@ static inline int arcvae_launch_status() {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- tuning knobs (read once per process; the captured hipGraph segments keep what they were recorded with) ----
+// ARCVAE_STEP_PRIO      0..3  s_setprio of the LSTM step kernels' waves: they share CUs with the side-stream GEMMs
+//                             and every cycle a step wave waits for an issue slot is on the dependent chain.
+// ARCVAE_SIDE_MAX_BLOCKS n    cap on resident blocks per CU of the kernels that run BESIDE the chain (weight-gradient
+//                             and decoder GEMMs, segment/column sums), enforced by padding their LDS allocation:
+//                             a step launch can only start on a CU that still has wave slots and registers free.
+#include <stdlib.h>
+static inline int arcvae_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+static inline int arcvae_step_prio() {
+    static const int v = arcvae_env_int("ARCVAE_STEP_PRIO", 0);
+    return v < 0 ? 0 : (v > 3 ? 3 : v);
+}
+static inline int arcvae_xcd_remap() {
+    static const int v = arcvae_env_int("ARCVAE_XCD_REMAP", 0);
+    return v != 0;
+}
+// dynamic-LDS pad (bytes) that limits a kernel with `own` bytes of LDS to the configured blocks per CU
+static inline unsigned arcvae_side_lds_pad(unsigned own) {
+    static const int n = arcvae_env_int("ARCVAE_SIDE_MAX_BLOCKS", 0);
+    if (n <= 0) return 0;
+    const unsigned cu_lds = 160u * 1024u, cap = 64u * 1024u;
+    unsigned want = cu_lds / (unsigned)n;          // n blocks fit, n+1 do not
+    want = (want / 512u) * 512u;
+    if (want > cap) want = cap;
+    if (cu_lds / want != (unsigned)n && want == cap) { /* n < 3 cannot be enforced below the 64 KB block limit */ }
+    return want > own + 512u ? want - own - 256u : 0u;
+}
+__device__ __forceinline__ void arcvae_set_prio(int p) {
+    if (p == 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+}
+
 // Accurate (non fast-math) transcendental forms: parity mode needs ~1-2 ulp expf/tanhf.
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 

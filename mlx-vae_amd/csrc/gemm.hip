@@ -240,14 +240,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
 
 template <int BM, int BN, bool AK, bool BKC>
 void launch_tile(const GemmP& p, dim3 grid, bool va4, bool vb4, hipStream_t s) {
+    const unsigned pad = arcvae_side_lds_pad(2 * BK * (BM + BN + 2 * PAD) * sizeof(float));
     if (va4 && vb4)
-        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 4, 4>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 4, 4>), grid, dim3(256), pad, s, p);
     else if (va4)
-        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 4, 1>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 4, 1>), grid, dim3(256), pad, s, p);
     else if (vb4)
-        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 1, 4>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 1, 4>), grid, dim3(256), pad, s, p);
     else
-        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 1, 1>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AK, BKC, 1, 1>), grid, dim3(256), pad, s, p);
 }
 
 template <int BM, int BN>
@@ -355,6 +356,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
     g.zoff[n] = ztot;
     for (int i = n; i < ARCVAE_GEMM_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.zoff[i + 1] = ztot; }
     dim3 grid(ceil_div(N, 64), ceil_div(M, 64), ztot);
-    hipLaunchKernelGGL((gemm_tile_group_kernel<64, 64, false, false, 4, 4>), grid, dim3(256), 0, stream, g);
+    const unsigned pad = arcvae_side_lds_pad(2 * BK * (64 + 64 + 2 * PAD) * sizeof(float));
+    hipLaunchKernelGGL((gemm_tile_group_kernel<64, 64, false, false, 4, 4>), grid, dim3(256), pad, stream, g);
     return arcvae_launch_status();
 }

@@ -24,6 +24,16 @@
 
 namespace {
 
+// XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one,
+// MI355X_MICROARCH.md "Workgroup dispatch"), and each XCD has its own L2.  A step block writes 16-byte (forward) or
+// 64-byte (BPTT) pieces of the activation rows, so with the identity mapping the 8 (2) blocks that together fill one
+// 128-B line sit on 8 (2) DIFFERENT XCDs: every L2 then writes back partial lines at the kernel boundary, which is
+// on the dependent chain.  With the mapping below neighbouring tiles share an XCD and its L2 merges them into whole
+// lines.  gx = gridDim.x must be a multiple of 8 (else identity).
+__device__ __forceinline__ int xcd_group_block(int x, int gx, int on) {
+    return (on && (gx & 7) == 0) ? (x & 7) * (gx >> 3) + (x >> 3) : x;
+}
+
 struct FwdJob {
     const float* xin;    // tiled [H/16][B][16]  h^{l-1}_t, or null for layer 0
     const float* Wx;     // tiled+permuted [H/16][4H][16]  (arcvae_tile_weights mode 0)
@@ -40,6 +50,8 @@ struct FwdJob {
 struct FwdArgs {
     FwdJob job[ARCVAE_MAX_LAYERS];
     int B, H, V;
+    int prio, remap;
+    unsigned long long* trace;  // diagnostic: {start, end} of block (0,0,0) in 100 MHz ticks, or null
 };
 
 // CH = H / 64: each of the 4 waves owns H/4 = 16*CH floats of K per source.
@@ -47,13 +59,17 @@ template <int CH>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     __shared__ float red[4 * 256];
     __shared__ float act[256];
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
     const FwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H;
-    const int r0 = blockIdx.y * 16, u0 = blockIdx.x * 4;
+    const int bx = xcd_group_block(blockIdx.x, gridDim.x, a.remap);
+    const int r0 = blockIdx.y * 16, u0 = bx * 4;
     const int arow = min(r0 + (lane & 15), B - 1);
     const int jc = lane & 15;
-    const int wrow = blockIdx.x * 16 + jc;  // permuted weight row of tile column jc (gate = jc>>2, unit = u0+(jc&3))
+    const int wrow = bx * 16 + jc;  // permuted weight row of tile column jc (gate = jc>>2, unit = u0+(jc&3))
     const bool s1 = j.xin != nullptr, s2 = j.hprev != nullptr;
     // Epilogue operands are requested FIRST (token -> table row is a dependent pair of loads, c_{t-1}
     // another cold line): their round trip then overlaps the operand loads instead of following the MFMAs.
@@ -96,6 +112,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
         j.ht[((long)(unit >> 4) * B + (r0 + crow)) * 16 + (unit & 15)] = hv;
         j.c[hb] = c;
     }
+    if (tr) a.trace[1] = wall_clock64();
 }
 
 // One BPTT launch carries up to 2L-1 single-source jobs (16 rows x 16 hidden units x K = 4H each):
@@ -123,16 +140,21 @@ struct BwdJob {
 struct BwdArgs {
     BwdJob job[ARCVAE_MAX_BWD_JOBS];
     int B, H;
+    int prio, remap;
+    unsigned long long* trace;
 };
 
 // 16 waves: wave w owns 4H/16 = 16*CH floats of the contraction index.
 template <int CH>
 __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     __shared__ float red[16 * 256];
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
     const BwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
-    const int r0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
+    const int r0 = blockIdx.y * 16, u0 = xcd_group_block(blockIdx.x, gridDim.x, a.remap) * 16;
     const int arow = min(r0 + (lane & 15), B - 1);
     const int wrow = u0 + (lane & 15);
     const bool cell = j.kind == 0;
@@ -185,6 +207,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
             tp[3 * gs] = d_o;
         }
     }
+    if (tr) a.trace[1] = wall_clock64();
 }
 
 template <int CH>
@@ -211,7 +234,23 @@ void launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t s) {
 
 inline bool hidden_ok(int H) { return H > 0 && (H % 64) == 0 && H <= 512; }
 
+// Diagnostic launch trace (tools/step_trace.py): slot s of the forward sweep at trace[2s..2s+1], of the BPTT sweep
+// at trace[2(cap/2 + s)..].  Set before the launches are recorded; null (default) = off.
+unsigned long long* g_trace = nullptr;
+int g_trace_cap = 0;
+inline unsigned long long* trace_slot(int slot) {
+    return (g_trace && slot >= 0 && slot < g_trace_cap) ? g_trace + 2 * (long)slot : nullptr;
+}
+
 }  // namespace
+
+// Diagnostic: device-side {start, end} stamps (100 MHz wall clock) of every step launch recorded after this call.
+// buf holds 2*cap u64; forward launch s -> slot s, BPTT launch s -> slot cap/2 + s.  buf = null switches it off.
+extern "C" int arcvae_set_step_trace(unsigned long long* buf, int cap) {
+    g_trace = buf;
+    g_trace_cap = buf ? cap : 0;
+    return ARCVAE_OK;
+}
 
 // Reference: models/encoder.py:98-101 (L stacked nn.LSTM over the full padded sequence, Q3).
 //   x_tb   [T,B] tokens (time-major)          table0 [V,4H] = emb . Wx_0^T + bias_0
@@ -255,7 +294,7 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     }
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
-        a.B = B; a.H = H; a.V = V;
+        a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(s);
         int nj = 0;
         for (int l = 0; l < L; ++l) {
             const int t = s - l;
@@ -315,7 +354,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     }
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
-        a.B = B; a.H = H;
+        a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(g_trace_cap / 2 + s);
         int nj = 0;
         for (int l = L - 1; l >= 0; --l) {
             const int skew = 2 * (L - 1 - l);

@@ -157,6 +157,41 @@ __global__ void zero2d_kernel(float* x, int rows, int cols, int ld) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[(i / cols) * ld + (i % cols)] = 0.f;
 }
 
+// ---- device-side gates: cross-stream ordering WITHOUT a blocked hardware queue --------------------------------
+// A stream that waits on another stream's event holds a barrier packet at the head of its hardware queue, and on
+// MI355X (ROCm 7.2) every such blocked queue adds ~1 us to EACH dependent dispatch of the chain that is running
+// (tools/step_trace.py: 4.72 -> 5.68 us per LSTM step launch).  A gate is instead a one-wave kernel that polls a
+// device word: the waiting queue is then "running", not "blocked".
+//   signal word  : a monotonically increasing u32 owned by the signalling stream (gate_set adds to it)
+//   ticket       : target = (*steps) * stride + offset, where `steps` is the WAITING stream's own count of steps it
+//                  has finished (advanced by its last gate of a step).  The kernel arguments are therefore the same
+//                  in every step and can live in a captured hipGraph while the host runs many steps ahead.
+// The spin is bounded (`max_polls`, ~1 us each): on expiry the gate raises err[0] and returns -- it can never hang
+// the device.  Two streams that share one hardware queue would deadlock a gate until that expiry, so the engine
+// probes each (waiter, signaller) pair with a short-fused gate before it relies on them (engine.py).
+__global__ __launch_bounds__(64) void gate_wait_kernel(const unsigned* flag, unsigned* steps, unsigned stride,
+                                                       unsigned offset, int advance, unsigned max_polls,
+                                                       unsigned* err) {
+    if (threadIdx.x != 0) return;
+    const unsigned n = steps ? __hip_atomic_load(steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const unsigned target = n * stride + offset;
+    bool ok = false;
+    for (unsigned i = 0; i < max_polls; ++i) {
+        const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (!ok && err) atomicAdd(err, 1u);
+    if (advance && steps) __hip_atomic_store(steps, n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__global__ __launch_bounds__(64) void gate_set_kernel(unsigned* flag, unsigned value, int add) {
+    if (threadIdx.x != 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (add) __hip_atomic_fetch_add(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void scale_kernel(float* x, long n, float s) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= s;
@@ -171,7 +206,7 @@ extern "C" int arcvae_colsum_accum(const float* X, int rows, int cols, int ld, f
     const int rpb = ceil_div(rows, nchunks);
     nchunks = ceil_div(rows, rpb);
     dim3 grid(ceil_div(cols, 64), nchunks);
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, rows, cols, ld, out, scale, rpb);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), arcvae_side_lds_pad(1024), stream, X, rows, cols, ld, out, scale, rpb);
     return arcvae_launch_status();
 }
 
@@ -210,7 +245,7 @@ extern "C" int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int 
     const size_t lds = (size_t)nseg * 64 * sizeof(float);
     if (lds > 64 * 1024) return ARCVAE_ERR_ARG;  // nseg <= 256 (vocabulary-sized segment counts)
     dim3 grid(ceil_div(cols, 64), ceil_div(rows, 256));
-    hipLaunchKernelGGL(segsum_kernel, grid, dim3(256), lds, stream, X, seg, rows, nseg, cols, out);
+    hipLaunchKernelGGL(segsum_kernel, grid, dim3(256), lds + arcvae_side_lds_pad((unsigned)lds), stream, X, seg, rows, nseg, cols, out);
     return arcvae_launch_status();
 }
 
@@ -243,6 +278,22 @@ extern "C" int arcvae_zero(float* x, int rows, int cols, int ld, hipStream_t str
     const long n = (long)rows * cols;
     const int blocks = (int)min((long)1024, (n + 255) / 256);
     hipLaunchKernelGGL(zero2d_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld);
+    return arcvae_launch_status();
+}
+
+// Device-side wait on `stream` until (int)(*flag - ((*steps) * stride + offset)) >= 0 (steps may be null: target =
+// offset); advance != 0: ++*steps afterwards.  max_polls bounds the spin (~1 us per poll); on expiry *err += 1.
+extern "C" int arcvae_gate_wait(const unsigned* flag, unsigned* steps, unsigned stride, unsigned offset, int advance,
+                                unsigned max_polls, unsigned* err, hipStream_t stream) {
+    if (!flag || max_polls == 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, stream, flag, steps, stride, offset, advance,
+                       max_polls, err);
+    return arcvae_launch_status();
+}
+// *flag = value (add == 0) or *flag += value, after everything earlier on `stream` (agent-scope release).
+extern "C" int arcvae_gate_set(unsigned* flag, unsigned value, int add, hipStream_t stream) {
+    if (!flag) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(gate_set_kernel, dim3(1), dim3(64), 0, stream, flag, value, add);
     return arcvae_launch_status();
 }
 
