@@ -117,6 +117,15 @@ def main():
                     help="run the data-parallel driver (process group + collectives) even at world size 1")
     args = ap.parse_args()
 
+    # Everything except the result line goes to stderr: RCCL prints its version banner on stdout at init.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str) -> None:
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
+
     import torch
     import torch.distributed as dist
     from arcvae_hip import _lib
@@ -190,7 +199,7 @@ def main():
     if args.roofline_only:
         one_step(0)
         torch.cuda.synchronize()
-        print(json.dumps({"roofline": roofline_probe(eng, ws, torch)}), flush=True)
+        emit(json.dumps({"roofline": roofline_probe(eng, ws, torch)}))
         return
     log(f"rank {rank}/{world}: warm-up ({args.warmup} steps, mode={mode})")
     for i in range(args.warmup):
@@ -242,7 +251,7 @@ def main():
         if args.cpu_steps > 0:
             log(f"cpu baseline on {host_cores()} host cores")
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()

@@ -8,12 +8,12 @@ step needs exactly two exchanges:
   1. forward seam : all-reduce(SUM) of `stats` (2Z+4 floats: sum mu, sum exp(logvar), KL sums,
                     row count, CE row-sum) -> every rank evaluates the GLOBAL loss scalars and
                     the MI gate, and differentiates them w.r.t. its LOCAL rows (1/B_global scaling);
-  2. backward     : all-reduce(SUM) of the flat gradient buffers, one bucket per module.  The
-                    decoder never reads z (Q2), so its whole forward+backward runs on the side
-                    stream and its bucket (3.9 MB) is reduced while the encoder BPTT sweep is still
-                    running on the main stream; the encoder bucket (5.3 MB) is the exposed tail.
-                    Messages are <= 5.3 MB: on point-to-point xGMI RCCL picks a direct
-                    reduce-scatter/all-gather rather than a per-link-bound ring.
+  2. backward     : all-reduce(SUM) of the flat gradient buffers -- ONE 9.2 MB bucket [enc.grad |
+                    dec.grad | CE sum] on the main stream behind the BPTT sweep (gated form, see
+                    EngineOps), or one bucket per module with the decoder's reduced on a comm stream
+                    beside the sweep (event form).  Messages are <= 9.2 MB: on point-to-point xGMI RCCL
+                    picks a direct reduce-scatter/all-gather rather than a per-link-bound ring (SURVEY
+                    section 5).
 
 Teacher-forcing coins, weights and Adam state must be identical on all ranks (same seed / same
 reduced gradients); `DataParallelStep` never touches them.
@@ -25,27 +25,34 @@ HIP engine (`EngineOps`) on the GPU.
 from __future__ import annotations
 
 import contextlib
+import ctypes as C
 import os
 from typing import ContextManager, List, Optional, Protocol
 
 import torch
 import torch.distributed as dist
 
+from ._lib import call, ptr, stream_ptr
+
 
 class StepOps(Protocol):
     stats: torch.Tensor        # per-rank partial latent sums (2Z+3 floats), all-reduced before the backward
-    recon_stat: torch.Tensor   # per-rank CE sum (1 float), all-reduced off the critical path
+    recon_stat: Optional[torch.Tensor]  # per-rank CE sum (1 float); None when it travels inside a gradient bucket
 
     def forward_local(self) -> None: ...      # fills self.stats with this rank's partial sums
     def backward_local(self) -> None: ...     # self.stats now holds GLOBAL sums; fills all gradients
     def early_buckets(self) -> List[torch.Tensor]: ...  # gradients ready before backward_local completes
     def late_buckets(self) -> List[torch.Tensor]: ...   # gradients ready after backward_local
     def early_context(self) -> ContextManager: ...      # stream context the early reduces are issued from
-    def recon_local(self) -> None: ...        # fills self.recon_stat (inside early_context)
-    def apply_update(self) -> None: ...       # self.recon_stat now holds the GLOBAL CE sum
+    def recon_local(self) -> None: ...        # fills the CE sum (inside early_context)
+    def apply_update(self) -> None: ...       # the CE sum is GLOBAL by now
 
 
 class DataParallelStep:
+    """Collectives are issued synchronously (async_op=False) under the stream context the ops choose: PyTorch then
+    runs an RCCL collective ON that stream, so no internal communication stream sits blocked on an event beside the
+    running LSTM chain (a blocked hardware queue costs ~1 us per dependent launch on MI355X, engine.Gates)."""
+
     def __init__(self, ops: StepOps, group: Optional[dist.ProcessGroup] = None):
         self.ops = ops
         self.group = group
@@ -53,36 +60,43 @@ class DataParallelStep:
         # exercise the collectives even at world size 1 (single-GPU rehearsal of the N-rank path)
         self.force = os.environ.get("ARCVAE_DP_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
 
-    def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
-        if self.world == 1 and not self.force:
-            return None
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+    def _all_reduce(self, t: Optional[torch.Tensor]) -> None:
+        if t is None or (self.world == 1 and not self.force):
+            return
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self) -> None:
         ops = self.ops
         ops.forward_local()
         self._all_reduce(ops.stats)                     # forward seam (critical path, 2Z+3 floats)
         ops.backward_local()
-        with ops.early_context():                       # decoder-side results: overlap the encoder BPTT
+        with ops.early_context():                       # decoder-side results
             ops.recon_local()
-            works = [self._all_reduce(ops.recon_stat, async_op=True)]
-            works += [self._all_reduce(g, async_op=True) for g in ops.early_buckets()]
+            self._all_reduce(ops.recon_stat)
+            for g in ops.early_buckets():
+                self._all_reduce(g)
         for g in ops.late_buckets():
             self._all_reduce(g)
-        for w in works:
-            if w is not None:
-                w.wait()
         ops.apply_update()
 
 
 class EngineOps:
     """StepOps over the HIP StepEngine (engine.py): the engine's phases with the collectives between.
 
-    main stream : [enc_fwd] -> (all-reduce stats) -> [loss + dcomb + sweep chunks...] -> (all-reduce enc.grad)
-                  -> [finalize + adam]
-    side stream : [dec_fwd] -> ev_chain -> [dec_bwd] -> ev_dec_bwd
-    aux stream  : [heads' and LSTM weight gradients, chunk by chunk behind the sweep]
-    comm stream : wait ev_chain -> recon sum -> (all-reduce) ; wait ev_dec_bwd -> (all-reduce dec.grad)
+    Gated form (default; engine.Gates -- side/aux wait in device-side gate kernels, no blocked hardware queue):
+      main stream : signal -> [enc_fwd] -> (all-reduce stats) -> [loss + dcomb + sweep chunks + signals]
+                    -> join aux, side -> [CE sum] -> (all-reduce ONE bucket: enc.grad | dec.grad | CE sum)
+                    -> [finalize + adam]
+      side stream : gate -> [dec_fwd + dec_bwd] ... gate -> [tail chunk's token-table half]
+      aux stream  : gate -> [weight gradients of chunk c] ...
+      Two collectives per step, both on the main stream.  The gradient bucket is one contiguous buffer (the stores'
+      `grad` tensors are re-pointed into it), so the whole backward exchange is a single 9.2 MB all-reduce behind
+      the sweep; the decoder's 3.9 MB share is not overlapped with the BPTT sweep any more (~2 % at 8 GPUs), which
+      buys a step without any cross-stream event wait while the chain runs.
+
+    Event form (fallback when the gate probe fails, ARCVAE_GATES=0): as in round 1 --
+      side: [dec_fwd] -> ev_chain -> [dec_bwd] -> ev_dec_bwd;  comm stream: CE sum and dec.grad reduced beside the
+      BPTT sweep;  enc.grad reduced after it.
     """
 
     def __init__(self, engine, ws, lr: float, global_rows: int, use_graph: bool = True):
@@ -90,11 +104,74 @@ class EngineOps:
         self.global_rows = int(global_rows)
         Z = engine.d.Z
         self.stats = ws.stats[:2 * Z + 3]
-        self.recon_stat = ws.stats[2 * Z + 3:2 * Z + 4]
         self.run = engine.runner(ws, lr, global_rows, capture=use_graph)
-        self.comm = torch.cuda.Stream(device=engine.device)
+        self.gated = engine.mode != "graph" and engine._gating_ok(torch.cuda.current_stream())
+        if self.gated:
+            self._make_bucket()
+            self.recon_stat = None
+        else:
+            self.recon_stat = ws.stats[2 * Z + 3:2 * Z + 4]
+            self.comm = torch.cuda.Stream(device=engine.device)
 
+    def _make_bucket(self) -> None:
+        """One contiguous gradient bucket [enc.grad | dec.grad | CE sum]; recorded segments hold the old pointers,
+        so every captured segment of the engine is dropped."""
+        eng = self.eng
+        ne, nd = eng.enc.numel_padded, eng.dec.numel_padded
+        cur = getattr(eng, "_dp_bucket", None)
+        if cur is None or cur.numel() != ne + nd + 64:
+            cur = torch.zeros(ne + nd + 64, dtype=torch.float32, device=eng.device)
+            cur[:ne].copy_(eng.enc.grad)
+            cur[ne:ne + nd].copy_(eng.dec.grad)
+            eng.enc.grad = cur[:ne]
+            eng.dec.grad = cur[ne:ne + nd]
+            eng._dp_bucket = cur
+            eng._runners.clear()
+            eng._graphs.clear()
+            self.run = eng.runner(self.ws, self.lr, self.global_rows, capture=self.run.capture)
+        self.bucket = cur
+        self.bucket_recon = cur[ne + nd:ne + nd + 1]
+
+    # ---- gated form ---------------------------------------------------------------------------------
+    def _grun(self, key, fn, stream) -> None:
+        self.run(f"gated:{key}", fn, stream)
+
+    def _forward_gated(self) -> None:
+        from .engine import EncoderBackwardPlan
+        eng, ws, g = self.eng, self.ws, self.eng.gates
+        nc = len(EncoderBackwardPlan(eng.enc, ws, eng.d).chunks)
+        g.signal(g.P, 1)
+        eng.enqueue_decoder(ws, self.global_rows, self._grun, wait_current=False, split_events=False,
+                            gate=(g, nc < 2))
+        eng.enqueue_encoder_forward(ws, self.run)
+
+    def _recon_gated(self) -> None:
+        # main has joined side and aux (enqueue_backward): CE row sums -> the bucket's last cell
+        eng, ws = self.eng, self.ws
+        Z = eng.d.Z
+        base = C.c_void_p(self.bucket_recon.data_ptr() - 4 * (2 * Z + 3))
+
+        def fn():
+            call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, base, Z, stream_ptr())
+        self.run("dp_recon", fn, torch.cuda.current_stream())
+
+    def _finish_gated(self) -> None:
+        from .engine import adam_update
+        eng, ws = self.eng, self.ws
+        Z = eng.d.Z
+
+        def fn():
+            ws.stats[2 * Z + 3:2 * Z + 4].copy_(self.bucket_recon)   # GLOBAL CE sum
+            call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), Z, ws.T, stream_ptr())
+            adam_update(eng.dec, self.lr)
+            adam_update(eng.enc, self.lr)
+        self.run("dp_finish", fn, torch.cuda.current_stream())
+
+    # ---- StepOps ----------------------------------------------------------------------------------------
     def forward_local(self) -> None:
+        if self.gated:
+            self._forward_gated()
+            return
         # same host order as the single-process step: decoder segments first (they only follow the input copies),
         # then the encoder forward, so the decoder overlaps the forward sweep
         self.eng.side.wait_stream(torch.cuda.current_stream())
@@ -102,25 +179,42 @@ class EngineOps:
         self.eng.enqueue_encoder_forward(self.ws, self.run)
 
     def backward_local(self) -> None:
+        if self.gated:
+            self.eng.enqueue_backward(self.ws, self._grun, gates=self.eng.gates)
+            torch.cuda.current_stream().wait_stream(self.eng.side)
+            return
         self.eng.enqueue_backward(self.ws, self.run)
 
     @contextlib.contextmanager
     def early_context(self):
+        if self.gated:
+            yield
+            return
         # decoder-side collectives are issued from the comm stream so they do not queue behind BPTT
         self.comm.wait_event(self.eng.ev_enc_fwd)  # the encoder forward zero-fills `stats` before the CE slot is set
         with torch.cuda.stream(self.comm):
             yield
 
     def recon_local(self) -> None:
+        if self.gated:
+            self._recon_gated()
+            return
         self.eng.enqueue_recon(self.ws, self.run)            # waits ev_chain on the comm stream
 
     def early_buckets(self) -> List[torch.Tensor]:
+        if self.gated:
+            return []
         torch.cuda.current_stream().wait_event(self.eng.ev_dec_bwd)
         return [self.eng.dec.grad]
 
     def late_buckets(self) -> List[torch.Tensor]:
+        if self.gated:
+            return [self.bucket]
         return [self.eng.enc.grad]
 
     def apply_update(self) -> None:
+        if self.gated:
+            self._finish_gated()
+            return
         torch.cuda.current_stream().wait_stream(self.comm)
         self.eng.enqueue_finish(self.ws, self.lr, True, self.run)

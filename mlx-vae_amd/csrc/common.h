@@ -22,6 +22,7 @@ static inline int arcvae_launch_status() {
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- tuning knobs (read once per process; the captured hipGraph segments keep what they were recorded with) ----
+// (defaults: ARCVAE_STEP_PRIO=3, ARCVAE_XCD_REMAP=1, ARCVAE_SIDE_MAX_BLOCKS=0 i.e. no cap)
 // ARCVAE_STEP_PRIO      0..3  s_setprio of the LSTM step kernels' waves: they share CUs with the side-stream GEMMs
 //                             and every cycle a step wave waits for an issue slot is on the dependent chain.
 // ARCVAE_SIDE_MAX_BLOCKS n    cap on resident blocks per CU of the kernels that run BESIDE the chain (weight-gradient
@@ -33,11 +34,11 @@ static inline int arcvae_env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 static inline int arcvae_step_prio() {
-    static const int v = arcvae_env_int("ARCVAE_STEP_PRIO", 0);
+    static const int v = arcvae_env_int("ARCVAE_STEP_PRIO", 3);
     return v < 0 ? 0 : (v > 3 ? 3 : v);
 }
 static inline int arcvae_xcd_remap() {
-    static const int v = arcvae_env_int("ARCVAE_XCD_REMAP", 0);
+    static const int v = arcvae_env_int("ARCVAE_XCD_REMAP", 1);
     return v != 0;
 }
 // dynamic-LDS pad (bytes) that limits a kernel with `own` bytes of LDS to the configured blocks per CU

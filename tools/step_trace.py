@@ -18,6 +18,8 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--H", type=int, default=Bn.H)
 ap.add_argument("--L", type=int, default=Bn.L)
 ap.add_argument("--Z", type=int, default=Bn.Z)
+ap.add_argument("--dp", action="store_true", help="trace the data-parallel driver (RCCL group of 1 rank, forced collectives)")
+ap.add_argument("--only-step", action="store_true", help="skip the calibration / hypothesis sections")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -40,9 +42,21 @@ ws.eps.copy_(torch.tensor(rs.standard_normal((B, Z)).astype(np.float32)))
 cap = 2 * (T + 2 * L + 4)
 buf = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
 _lib.call("arcvae_set_step_trace", _lib.ptr(buf), cap)
+if args.dp:
+    import torch.distributed as dist
+    from arcvae_hip.dp import DataParallelStep, EngineOps
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+    os.environ["ARCVAE_DP_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dp = DataParallelStep(EngineOps(eng, ws, Bn.LR, B, use_graph=True))
+    print("dp gated:", dp.ops.gated)
+    step_fn = dp.step
+else:
+    step_fn = lambda: eng.run_step(ws, Bn.LR, update=True)
 for _ in range(args.steps):
-    eng.run_step(ws, Bn.LR, update=True)
+    step_fn()
 torch.cuda.synchronize()
+eng.check_gates()
 t = buf.cpu().numpy().reshape(cap, 2).astype(np.float64) / 100.0  # us
 nf, nb = T + L - 1, T + 2 * (L - 1)
 fw, bw = t[:nf], t[cap // 2: cap // 2 + nb]
@@ -61,6 +75,10 @@ def stats(name, a):
 stats("forward sweep", fw)
 stats("BPTT sweep", bw)
 print(f"forward end -> BPTT start: {bw[0,0]-fw[-1,1]:.1f} us;  step (first fwd launch -> last bwd launch end): {bw[-1,1]:.1f} us")
+if args.dp:
+    dist.destroy_process_group()
+if args.only_step or args.dp:
+    sys.exit(0)
 
 # ---- calibration: the same sweeps replayed ALONE (one linear graph each, nothing else on the chip) ----
 def alone(name, fn, n, off):
