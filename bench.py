@@ -105,7 +105,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="default 64 (512 with --config big)")
+    ap.add_argument("--config", choices=["default", "big"], default="default",
+                    help="default = BASELINE.json configs[1]; big = configs[2] (H512 Z256 L4, bs 512: MFMA-bound regime)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mode", choices=["auto", "graph", "eager", "segments"], default="auto",
                     help="launch mode: one multi-stream hipGraph, eager launches, or per-stream graph segments")
@@ -152,7 +154,14 @@ def main():
             os.environ["ARCVAE_DP_FORCE_COLLECTIVES"] = "1"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B = args.batch_per_gpu
+    global H, Z, L
+    if args.config == "big":
+        H, Z, L = 512, 256, 4
+    B = args.batch_per_gpu or (512 if args.config == "big" else 64)
+    wl_name = ("default AR-CVAE V80 E128 H256 Z128 C1 L2" if args.config == "default"
+               else "big AR-CVAE V80 E128 H512 Z256 C1 L4")
+    wl_ref = "BASELINE.json configs[1]" if (args.config == "default" and B == 64) else (
+        "BASELINE.json configs[2]" if (args.config == "big" and B == 512) else "non-headline batch size")
     dims = E.ModelDims(V=V, E=EMB, H=H, Z=Z, C=C, L=L)
     gen = torch.Generator().manual_seed(1234)  # identical initial weights on every rank
     enc = ParamStore(encoder_shapes(V, EMB, H, Z, C, L), dev)
@@ -235,8 +244,8 @@ def main():
             "value": seqs, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "default AR-CVAE V80 E128 H256 Z128 C1 L2, bs 64/GPU, T 128, tf 0.9, "
-                                   "beta 0 (epoch-0 schedule), fwd+bwd+Adam (BASELINE.json configs[1])",
+            "config": {"workload": f"{wl_name}, bs {B}/GPU, T 128, tf 0.9, "
+                                   f"beta 0 (epoch-0 schedule), fwd+bwd+Adam ({wl_ref})",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
                        "launch_mode": mode},
             "elbo": {"total": float(scal[0]), "recon": float(scal[1]), "kl": float(scal[2]),
@@ -248,7 +257,7 @@ def main():
         if not args.no_roofline:
             out["roofline"] = roofline_probe(eng, ws, torch)
             log("roofline probe done")
-        if args.cpu_steps > 0:
+        if args.cpu_steps > 0 and args.config == "default":
             log(f"cpu baseline on {host_cores()} host cores")
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         emit(json.dumps(out))

@@ -543,7 +543,8 @@ class StepEngine:
 
     # ---- the phases of a step (data-parallel collectives go between them, dp.py) ------------------------
     def enqueue_decoder(self, ws: Workspace, global_rows: int, run=_inline, backward: bool = True,
-                        wait_current: bool = True, split_events: bool = True, gate=None) -> None:
+                        wait_current: bool = True, split_events: bool = True, gate=None,
+                        adam_lr: Optional[float] = None) -> None:
         """Dense decoder on the side stream: forward + TF walk + CE row sums (ev_chain), then its whole backward
         (ev_dec_bwd).  Independent of the encoder (Q2); it only has to follow the input copies."""
         d = self.d
@@ -560,6 +561,8 @@ class StepEngine:
 
         def dec_bwd():
             decoder_backward(self.dec, ws, d, 1.0 / (global_rows * ws.T))
+            if adam_lr is not None:
+                adam_update(self.dec, adam_lr)
 
         if backward and not split_events:  # single process: one side-stream segment (one graph launch less)
             run("dec_all", lambda: (dec_fwd(), dec_bwd()), self.side)
@@ -609,7 +612,8 @@ class StepEngine:
     def _recon(self, ws: Workspace) -> None:
         call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z, stream_ptr())
 
-    def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline, with_recon: bool = False) -> None:
+    def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline, with_recon: bool = False,
+                       dec_adam: bool = True) -> None:
         """[CE sum ->] recon/total scalars, join the side stream, both Adam updates: one segment."""
         main = torch.cuda.current_stream()
         main.wait_stream(self.side)
@@ -619,7 +623,8 @@ class StepEngine:
                 self._recon(ws)
             call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
             if update:
-                adam_update(self.dec, lr)
+                if dec_adam:
+                    adam_update(self.dec, lr)
                 adam_update(self.enc, lr)
 
         run(("finish" if update else "finish_noupdate") + ("_r" if with_recon else ""), fin, main)
@@ -638,10 +643,13 @@ class StepEngine:
                 _run(f"gated:{key}", fn, stream)
 
             g.signal(g.P, 1)                                 # signal #1: the input copies are done (plain launch)
-            self.enqueue_decoder(ws, global_rows, grun, wait_current=False, split_events=False, gate=(g, nc < 2))
-            self.enqueue_encoder_forward(ws, run)
-            self.enqueue_backward(ws, grun, gates=g)
-            self.enqueue_finish(ws, lr, update, run, with_recon=True)
+            # the decoder's Adam update rides at the end of its own segment (its gradients are complete ~1 ms
+            # before the encoder's): one launch less in the exposed tail of the step
+            self.enqueue_decoder(ws, global_rows, grun, wait_current=False, split_events=False, gate=(g, nc < 2),
+                                 adam_lr=lr if update else None)
+            # encoder forward + loss + dcomb + first sweep chunk as ONE segment (no seam between the sweeps)
+            self.enqueue_backward(ws, grun, gates=g, fuse_forward=True)
+            self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False)
             return
         self.side.wait_stream(main)                          # the decoder only has to follow the input copies
         self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)

@@ -303,7 +303,8 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     dim3 grid(ceil_div(N, bn), ceil_div(M, bm), 1);
     if ((flags & ARCVAE_GEMM_SPLITK) && p.act == 0) {
         const int blocks = grid.x * grid.y;
-        int want = ceil_div(512, blocks);
+        static const int target = arcvae_env_int("ARCVAE_SPLITK_BLOCKS", 512);
+        int want = ceil_div(target, blocks);
         const int maxz = max(1, K / 128);  // at least 128 of K per slice
         int z = min(want, maxz);
         if (z > 1) {
@@ -346,7 +347,8 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
         p.A = A[i]; p.B = B[i]; p.C = C[i]; p.bias = nullptr;
         p.M = M; p.N = N; p.K = K[i]; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
         p.accumulate = 1; p.act = 0;
-        int z = min(ceil_div(512, tiles * n), max(1, K[i] / 128));
+        static const int target = arcvae_env_int("ARCVAE_GROUP_BLOCKS", 512);
+        int z = min(ceil_div(target, tiles * n), max(1, K[i] / 128));
         z = max(1, z);
         p.kchunk = ceil_div(ceil_div(K[i], z), BK) * BK;
         z = ceil_div(K[i], p.kchunk);

@@ -1,0 +1,94 @@
+"""Device-side gates (engine.Gates, csrc/misc.hip gate_wait/gate_set): the cross-stream ordering of the step
+without event waits.  No reference counterpart (the reference is one lazy MLX graph); the contract is that the
+gated step computes exactly what the event-ordered step computes, and that a gate can never hang."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import HYPER, SMALL, TINY, build_engine, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _word(t, i=0):
+    return C.c_void_p(t.data_ptr() + 4 * i)
+
+
+def test_gate_kernel_semantics():
+    from arcvae_hip import _lib
+    s = _lib.stream_ptr()
+    mem = torch.zeros(8, dtype=torch.int32, device="cuda")  # [0] flag, [1] steps, [2] err
+    # already satisfied: returns at once, no error; advance bumps the waiter's step count
+    _lib.call("arcvae_gate_set", _word(mem, 0), 5, 0, s)
+    _lib.call("arcvae_gate_wait", _word(mem, 0), _word(mem, 1), 4, 1, 1, 1000, _word(mem, 2), s)
+    torch.cuda.synchronize()
+    assert mem[:3].tolist() == [5, 1, 0]
+    # ticket of the next step: target = 1*4 + 2 = 6 > 5 -> expires (bounded spin), raises err, still advances
+    _lib.call("arcvae_gate_wait", _word(mem, 0), _word(mem, 1), 4, 2, 1, 200, _word(mem, 2), s)
+    torch.cuda.synchronize()
+    assert mem[:3].tolist() == [5, 2, 1]
+    # add-mode signal; wrap-around compare: flag far "behind" in unsigned terms is still behind
+    _lib.call("arcvae_gate_set", _word(mem, 0), 7, 1, s)
+    torch.cuda.synchronize()
+    assert int(mem[0]) == 12
+    mem[0] = -3  # 0xFFFFFFFD
+    _lib.call("arcvae_gate_wait", _word(mem, 0), C.c_void_p(0), 0, 2, 0, 200, _word(mem, 2), s)  # target 2 is AHEAD
+    torch.cuda.synchronize()
+    assert int(mem[2]) == 2
+    with pytest.raises(_lib.ArcvaeHipError):
+        _lib.call("arcvae_gate_wait", C.c_void_p(0), C.c_void_p(0), 0, 1, 0, 10, C.c_void_p(0), s)
+
+
+def test_gate_released_from_another_stream():
+    from arcvae_hip.engine import Gates
+    g = Gates(torch.device("cuda"))
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    # some pair of pool streams sits on distinct hardware queues; the probe must find it and never hang
+    ok = any(g.probe(torch.cuda.Stream(), torch.cuda.current_stream()) for _ in range(8)) or g.probe(a, b)
+    assert ok
+    assert g.errors() == 0  # the probe restores the error word
+
+
+@pytest.mark.parametrize("cfg,B,T", [(TINY, 5, 12), (SMALL, 9, 10)])
+def test_gated_step_equals_event_ordered_step(cfg, B, T, monkeypatch):
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    res = {}
+    for gates in ("1", "0"):
+        monkeypatch.setenv("ARCVAE_GATES", gates)
+        eng, enc, dec = build_engine(cfg, params)
+        assert (eng.gates is not None) == (gates == "1")
+        losses = []
+        for _ in range(4):  # step 1 runs eagerly, later steps replay the captured segments
+            eng.train_step(x, cond, eps, coins, lr=2e-4, **HYPER)
+            torch.cuda.synchronize()
+            losses.append(eng.workspace(B, T).scalars.cpu().numpy()[:9].copy())
+        eng.check_gates()
+        if gates == "1":
+            assert eng._gating_ok(torch.cuda.current_stream()), "no distinct hardware queues found on this box"
+            P, Q, NS, NA = (int(eng.gates.mem[32 * i]) for i in range(4))
+            assert (P, Q, NS, NA) == (4 * eng.gates.STRIDE, 4, 4, 4)
+        res[gates] = (np.stack(losses), enc.flat.cpu().numpy(), dec.flat.cpu().numpy(), enc.grad.cpu().numpy())
+    a, b = res["1"], res["0"]
+    assert np.allclose(a[0], b[0], rtol=2e-5, atol=2e-6)
+    for i in (1, 2, 3):
+        assert rel_err(a[i], b[i]) < 1e-5
+
+
+def test_gated_steps_across_workspaces_keep_tickets_in_step():
+    """Different (B,T) workspaces (ragged last batch, different chunk counts) share the engine's gate words."""
+    cfg = TINY
+    params, x, cond, eps, coins = make_case(cfg, 8, 12, 0.6)
+    eng, enc, dec = build_engine(cfg, params)
+    n = 0
+    for B, T in [(8, 12), (3, 12), (8, 3), (8, 12), (1, 1), (3, 12)]:
+        coins_t = coins[:T] if T <= len(coins) else coins
+        eng.train_step(x[:B, :T], cond[:B], eps[:B], coins_t, lr=2e-4, **HYPER)
+        n += 1
+    torch.cuda.synchronize()
+    eng.check_gates()
+    if eng._gating_ok(torch.cuda.current_stream()):
+        P, Q, NS, NA = (int(eng.gates.mem[32 * i]) for i in range(4))
+        assert (P, Q, NS, NA) == (n * eng.gates.STRIDE, n, n, n)
+    assert np.isfinite(eng.workspace(3, 12).scalars.cpu().numpy()[:9]).all()
