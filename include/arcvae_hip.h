@@ -77,9 +77,10 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,
  * lstm_layer_l.{Wx,Wh,bias}; `first` zeroes the token-table workspace, `last` folds it into the
- * embedding / layer-0 gradients. */
+ * embedding / layer-0 gradients.  dtable_ws [V,4H]; onehot_ws [T*B, roundup(V,4)] (one-hot token rows, written
+ * when `first`: the token segment-sum runs as OneHot^T . dG_0 on the matrix cores). */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
-                          const float* dG, float* dtable_ws, float* dEmb, float* const* dWx,
+                          const float* dG, float* dtable_ws, float* onehot_ws, float* dEmb, float* const* dWx,
                           float* const* dWh, float* const* dbias, int B, int T, int V, int E, int H, int L,
                           int t_lo, int t_hi, int first, int last, int parts /* 1 layers | 2 token table */,
                           arcvae_stream_t stream);

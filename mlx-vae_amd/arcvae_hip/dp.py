@@ -180,8 +180,7 @@ class EngineOps:
 
     def backward_local(self) -> None:
         if self.gated:
-            self.eng.enqueue_backward(self.ws, self._grun, gates=self.eng.gates)
-            torch.cuda.current_stream().wait_stream(self.eng.side)
+            self.eng.enqueue_backward(self.ws, self._grun, gates=self.eng.gates)  # ends with the gate join on R
             return
         self.eng.enqueue_backward(self.ws, self.run)
 

@@ -108,6 +108,7 @@ class Workspace:
             self.dxs = torch.empty(L, T, B, H, **f32)
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
             self.dtable0 = torch.empty(V, G, **f32)
+            self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)
             self.dlogits = torch.empty(BV, V, **f32)
             self.ddh = torch.empty(2, BV, H, **f32)
             self.ddG = torch.empty(BV, G, **f32)
@@ -199,14 +200,15 @@ class Gates:
     almost all the time).  With gates the waiting stream runs a one-wave polling kernel instead.
 
     Words (one 128-B line each):  P main's signal count (exactly STRIDE per step), Q aux's (1 per step),
-    NS / NA steps finished by side / aux (the waiter's own ticket counter), ERR expired gates, PROBE self-test.
+    R completions of aux + side (2 per step: main's join before the optimizer step), NS / NA / NM steps finished by
+    side / aux / main (the waiter's own ticket counter), ERR expired gates, PROBE self-test.
     """
     STRIDE = 8
     LONG, SHORT = 4_000_000, 3_000     # polls (~1 us each): ~4 s before a gate gives up; ~3 ms for the probe
-    P, Q, NS, NA, ERR, PROBE = range(6)
+    P, Q, NS, NA, ERR, PROBE, R, NM = range(8)
 
     def __init__(self, device):
-        self.mem = torch.zeros(6 * 32, dtype=torch.int32, device=device)
+        self.mem = torch.zeros(8 * 32, dtype=torch.int32, device=device)
         self._probed: Dict[Tuple[int, int], bool] = {}
 
     def word(self, i: int) -> C.c_void_p:
@@ -327,7 +329,8 @@ class EncoderBackwardPlan:
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3) -> None:
         enc, ws, d = self.enc, self.ws, self.d
         call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
-             ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(enc.g("embedding.weight")), self._dwx[0], self._dwh[0],
+             ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(ws.onehot), ptr(enc.g("embedding.weight")), self._dwx[0],
+             self._dwh[0],
              self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), parts, stream_ptr())
 
 
@@ -392,8 +395,8 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     #1 inputs ready (enqueued by the caller), #(2+c) after sweep chunk c, the last chunk topping P up to a multiple
     of STRIDE.  aux: chunk c runs behind signal #(2+c); it signals Q once (after its last-but-one chunk).  side:
     the tail chunk's token-table half runs behind Q (the table accumulates across aux's earlier chunks) and the last
-    signal.  The current stream joins aux (and the caller joins side) with ordinary events at the very end, when the
-    chain is over."""
+    signal.  aux and side report their last piece of the step on R; the current stream joins them with a gate
+    on R at the very end (the decoder segment precedes side's tail piece in stream order, so R covers it too)."""
     main = torch.cuda.current_stream()
     nc = len(plan.chunks)
     if nc + 1 > g.STRIDE:
@@ -415,11 +418,14 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             plan.wgrad(t_lo, t_hi, first, last, 1 if (last and tail_on_side) else 3)
             if c == max(nc - 2, 0):
                 g.signal(g.Q, 1)
+            if last:
+                g.signal(g.R, 1 if tail_on_side else 2)
 
         def side_seg(t_lo=t_lo, t_hi=t_hi, first=first, last=last):
             g.wait(g.Q, g.NS, 1, 1)
             g.wait(g.P, g.NS, g.STRIDE, g.STRIDE, advance=True)
             plan.wgrad(t_lo, t_hi, first, last, 2)
+            g.signal(g.R, 1)
 
         run(f"main{c}", main_seg, main)
         if c == 0 and after_first:
@@ -427,9 +433,10 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
         if last and tail_on_side:
             run(f"aux2_{c}", side_seg, aux2)
         run(f"aux{c}", aux_seg, aux)
-    main.wait_stream(aux)
-    if aux2 is not None:
-        main.wait_stream(aux2)
+    # join: main polls R (a gate reacts within ~2 us; an event wait on two other queues cost ~20 us of the tail)
+    run("join", lambda: g.wait(g.R, g.NM, 2, 2, advance=True), main)
+    if aux2 is not None and not tail_on_side:
+        main.wait_stream(aux2)  # single-chunk sweeps (T <= 3): side only ran the decoder and reported nothing
 
 
 def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
@@ -613,10 +620,11 @@ class StepEngine:
         call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z, stream_ptr())
 
     def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline, with_recon: bool = False,
-                       dec_adam: bool = True) -> None:
+                       dec_adam: bool = True, join_side: bool = True) -> None:
         """[CE sum ->] recon/total scalars, join the side stream, both Adam updates: one segment."""
         main = torch.cuda.current_stream()
-        main.wait_stream(self.side)
+        if join_side:
+            main.wait_stream(self.side)
 
         def fin():
             if with_recon:
@@ -649,7 +657,7 @@ class StepEngine:
                                  adam_lr=lr if update else None)
             # encoder forward + loss + dcomb + first sweep chunk as ONE segment (no seam between the sweeps)
             self.enqueue_backward(ws, grun, gates=g, fuse_forward=True)
-            self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False)
+            self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False)
             return
         self.side.wait_stream(main)                          # the decoder only has to follow the input copies
         self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)

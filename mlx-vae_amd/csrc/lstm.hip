@@ -210,6 +210,20 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     if (tr) a.trace[1] = wall_clock64();
 }
 
+// One-hot rows of the layer-0 tokens: oh[r, v] = (tok[r] == v), r = t*B + b, row stride Vp (V rounded up to 4).
+// The token segment-sum dTable0[v] = sum_{r: tok=v} dG_0[r] is then OneHot^T . dG_0 on the matrix cores (split-K
+// GEMM, K = rows of the chunk) instead of an LDS-atomic scatter with a global-atomic flush per block: 26 -> ~10 us
+// per BPTT chunk and, above all, 38 -> ~10 us in the exposed tail of the step.
+__global__ __launch_bounds__(256) void onehot_kernel(const int32_t* __restrict__ tok, int rows, int V, int Vp,
+                                                     float* __restrict__ oh) {
+    const long n = (long)rows * Vp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / Vp), v = (int)(i - (long)r * Vp);
+        const int tk = min(max(tok[r], 0), V - 1);
+        oh[i] = (v == tk) ? 1.0f : 0.0f;
+    }
+}
+
 template <int CH>
 void launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(lstm_fwd_step_kernel<CH>, grid, dim3(256), 0, s, a);
@@ -271,24 +285,22 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
     const long wsz = (long)H * 4 * H;
-    {   // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz
-        const float* src[16];
-        float* dst[16];
-        int cols[16], mode[16];
+    {   // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz; with wT_bwd also the BPTT
+        // layouts of the same weights (keeps that launch off the chain between the sweeps) -- one launch for both
+        // when the 2(2L-1) jobs fit (L <= 4)
+        const float* src[32];
+        float* dst[32];
+        int cols[32], mode[32];
         int n = 0;
-        for (int l = 0; l < L; ++l) {
-            src[n] = Wh[l]; dst[n] = wt + l * wsz; cols[n] = H; mode[n] = 0; ++n;
-            if (l > 0) { src[n] = Wx[l]; dst[n] = wt + (L + l - 1) * wsz; cols[n] = H; mode[n] = 0; ++n; }
-        }
-        int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
-        if (rc != ARCVAE_OK) return rc;
-        if (wT_bwd) {  // the BPTT layouts too (same weights): keeps this launch off the chain between the sweeps
-            n = 0;
+        for (int pass = 0; pass < (wT_bwd ? 2 : 1); ++pass) {
+            float* base = pass == 0 ? wt : wT_bwd;
             for (int l = 0; l < L; ++l) {
-                src[n] = Wh[l]; dst[n] = wT_bwd + l * wsz; cols[n] = H; mode[n] = 1; ++n;
-                if (l > 0) { src[n] = Wx[l]; dst[n] = wT_bwd + (L + l - 1) * wsz; cols[n] = H; mode[n] = 1; ++n; }
+                src[n] = Wh[l]; dst[n] = base + l * wsz; cols[n] = H; mode[n] = pass; ++n;
+                if (l > 0) { src[n] = Wx[l]; dst[n] = base + (L + l - 1) * wsz; cols[n] = H; mode[n] = pass; ++n; }
             }
-            rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
+        }
+        for (int i = 0; i < n; i += 16) {
+            const int rc = arcvae_tile_weights(src + i, dst + i, cols + i, mode + i, n - i < 16 ? n - i : 16, H, stream);
             if (rc != ARCVAE_OK) return rc;
         }
     }
@@ -401,19 +413,26 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   l == 0: dTable0[v] += sum_{(t,b): x=v} dG_0[t,b]   (dtable_ws [V,4H], zeroed when `first` != 0)
 //   when `last` != 0 (all ranges done): dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;  dbias_0 += colsum(dTable0)
 //   parts: bit 0 = the per-layer GEMMs, bit 1 = the layer-0 token-table path (they are independent: two streams)
+//   onehot_ws [T*B, roundup(V,4)] workspace: one-hot token rows, written when `first` != 0 (token-table part)
 extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0,
-                                     const float* hseq, const float* dG, float* dtable_ws, float* dEmb,
-                                     float* const* dWx, float* const* dWh, float* const* dbias, int B, int T,
-                                     int V, int E, int H, int L, int t_lo, int t_hi, int first, int last,
-                                     int parts, hipStream_t stream) {
-    if (!x_tb || !emb || !Wx0 || !hseq || !dG || !dtable_ws || !dEmb || !dWx || !dWh || !dbias)
+                                     const float* hseq, const float* dG, float* dtable_ws, float* onehot_ws,
+                                     float* dEmb, float* const* dWx, float* const* dWh, float* const* dbias,
+                                     int B, int T, int V, int E, int H, int L, int t_lo, int t_hi, int first,
+                                     int last, int parts, hipStream_t stream) {
+    if (!x_tb || !emb || !Wx0 || !hseq || !dG || !dtable_ws || !onehot_ws || !dEmb || !dWx || !dWh || !dbias)
         return ARCVAE_ERR_ARG;
     if (t_lo < 0 || t_hi > T || t_lo > t_hi) return ARCVAE_ERR_ARG;
     const int G = 4 * H, TB = T * B;
     const long lH = (long)TB * H, lG = (long)TB * G;
     int rc;
     const bool do_layers = (parts & 1) != 0, do_table = (parts & 2) != 0;
-    if (do_table && first && arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+    const int Vp = (V + 3) & ~3;
+    if (do_table && first) {
+        if (arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+        const long n = (long)TB * Vp;
+        hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, stream, x_tb,
+                           TB, V, Vp, onehot_ws);
+    }
     if (t_hi > t_lo) {
         const int nt = t_hi - t_lo;
         if (do_layers) {  // all per-layer weight-gradient GEMMs of this time range in ONE grouped launch
@@ -444,9 +463,9 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                 if (rc) return rc;
             }
         }
-        if (do_table) {
-            rc = arcvae_segsum_rows_accum(dG + (long)t_lo * B * G, x_tb + (long)t_lo * B, nt * B, V, G, dtable_ws,
-                                          stream);
+        if (do_table) {  // dTable0 += OneHot[rows]^T . dG_0[rows]   (see onehot_kernel)
+            rc = arcvae_gemm_f32(1, 0, V, G, nt * B, onehot_ws + (long)t_lo * B * Vp, Vp, dG + (long)t_lo * B * G, G,
+                                 dtable_ws, G, nullptr, ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK, stream);
             if (rc) return rc;
         }
     }
