@@ -168,6 +168,11 @@ int arcvae_transpose_batched(const float* const* src, float* const* dst, const i
                              int n, arcvae_stream_t stream);
 int arcvae_scale_inplace(float* x, long n, float s, arcvae_stream_t stream);
 int arcvae_zero(float* x, int rows, int cols, int ld, arcvae_stream_t stream);
+/* Token-table gradient dT [V,4H] of an LSTM layer-0 input projection folded back in one launch (backward of
+ * nn.Embedding + the x.Wx^T term of nn.LSTM, models/encoder.py:93,98 and models/decoder.py:154-166):
+ * dEmb [V,E] += dT . Wx0[:, :E];  dWx0[:, :E] += dT^T . emb (row stride ldw);  db0 [4H] += colsum(dT).  V <= 128. */
+int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw, const float* emb, float* dEmb, float* dWx0,
+                          float* db0, int V, int E, int G, arcvae_stream_t stream);
 /* Device-side gates (no reference counterpart): cross-stream ordering by a one-wave polling kernel instead of an
  * event wait, because a hardware queue blocked on an event slows every dependent dispatch of the chain that is
  * running.  wait: returns once (int)(*flag - ((*steps) * stride + offset)) >= 0 (steps may be

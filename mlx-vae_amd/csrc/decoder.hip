@@ -443,17 +443,11 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
     }
     hipLaunchKernelGGL(dec_l0_bwd_kernel, dim3(ceil_div(H, 64), V), dim3(256), 0, stream, tableD, cond, Wx[0],
                        bias[0], dhA, dtableD, wcpart, B, V, E, C, H);
-    rc = arcvae_colsum_accum(dtableD, V, G, G, dbias[0], 1.0f, stream);
-    if (rc) return rc;
     if (C > 0)
         hipLaunchKernelGGL(dec_wc_reduce_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, stream, wcpart, dWx[0],
                            V, G, E, C);
-    // dEmb += dTableD . Wx0[:, :E]        (M=V, N=E, K=4H; B operand = Wx0 [4H, E+C] row-major, ld E+C)
-    rc = arcvae_gemm_f32(0, 0, V, E, G, dtableD, G, Wx[0], E + C, dEmb, E, nullptr,
-                         ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_NO_SKINNY, stream);
-    if (rc) return rc;
-    // dWx0[:, :E] += dTableD^T . Emb      (M=4H, N=E, K=V; C has ld E+C)
-    rc = arcvae_gemm_f32(1, 0, G, E, V, dtableD, G, emb, E, dWx[0], E + C, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
+    // dEmb += dTableD . Wx0[:, :E];  dWx0[:, :E] += dTableD^T . Emb (ld E + C);  dbias_0 += colsum(dTableD)
+    rc = arcvae_table_finalize(dtableD, Wx[0], E + C, emb, dEmb, dWx[0], dbias[0], V, E, G, stream);
     if (rc) return rc;
     return arcvae_launch_status();
 }

@@ -469,13 +469,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
             if (rc) return rc;
         }
     }
-    if (last && do_table) {
-        rc = arcvae_gemm_f32(0, 0, V, E, G, dtable_ws, G, Wx0, E, dEmb, E, nullptr,
-                             ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_NO_SKINNY, stream);
-        if (rc) return rc;
-        rc = arcvae_gemm_f32(1, 0, G, E, V, dtable_ws, G, emb, E, dWx[0], E, nullptr, ARCVAE_GEMM_ACCUMULATE, stream);
-        if (rc) return rc;
-        return arcvae_colsum_accum(dtable_ws, V, G, G, dbias[0], 1.0f, stream);
-    }
+    if (last && do_table)
+        return arcvae_table_finalize(dtable_ws, Wx0, E, emb, dEmb, dWx[0], dbias[0], V, E, G, stream);
     return arcvae_launch_status();
 }

@@ -107,6 +107,99 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ X
     }
 }
 
+// ---- token-table gradient -> embedding / layer-0 input-weight / bias gradients, ONE launch ------------------
+// The layer-0 input projection of an LSTM is a [V,4H] table (emb . Wx0^T + b0), so its gradient arrives as
+// dT [V,4H] and is folded back with three tiny products (42 MFLOP at the default shape):
+//   dEmb [V,E]   += dT . Wx0[:, :E]          (K = 4H)
+//   dWx0 [4H,E]  += dT^T . Emb               (K = V)       (row stride ldw = E or E + C)
+//   db0  [4H]    += colsum(dT)
+// As three split-K tile-GEMM / colsum launches they cost 13 + 17 + 7 us of pure launch and pipeline latency --
+// in the encoder that is the exposed tail of the training step.  Here: one launch of plain f32 FMAs with every
+// operand staged through LDS first (no global load inside an FMA loop).  Block roles by blockIdx.x:
+//   [0, nA)        dEmb : 4 table rows x 128 embedding columns x one 64-wide slice of K = 4H; f32 atomics over slices
+//   [nA, nA+nB)    dWx0 : 16 gate rows x 128 embedding columns, K = V
+//   [nA+nB, ...)   db0  : 256 gate columns each
+constexpr int TF_ROWS = 4;
+constexpr int TF_KS = 64;
+__global__ __launch_bounds__(256) void table_finalize_kernel(const float* __restrict__ dT, const float* __restrict__ Wx0,
+                                                             int ldw, const float* __restrict__ emb, float* dEmb,
+                                                             float* dWx0, float* db0, int V, int E, int G, int nA,
+                                                             int nB, int etiles) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int tid = threadIdx.x, e_l = tid & 127, half = tid >> 7;
+    int bid = blockIdx.x;
+    if (bid < nA) {                                   // ---- dEmb
+        const int kslices = G / TF_KS;
+        const int ks = bid % kslices, et = (bid / kslices) % etiles, v0 = (bid / (kslices * etiles)) * TF_ROWS;
+        const int k0 = ks * TF_KS, e0 = et * 128, e = e0 + e_l;
+        float* wt = sh;                               // Wx0 tile [TF_KS][128]
+        float* tt = sh + TF_KS * 128;                 // dT tile  [TF_ROWS][TF_KS]
+        float* red = tt + TF_ROWS * TF_KS;            // [TF_ROWS][128] partials of half 1
+        for (int i = tid; i < TF_KS * 128; i += 256) {
+            const int kk = i >> 7, ee = i & 127;
+            wt[i] = (e0 + ee < E) ? Wx0[(long)(k0 + kk) * ldw + e0 + ee] : 0.f;
+        }
+        {
+            const int r = tid / TF_KS, kk = tid % TF_KS;  // 256 = TF_ROWS * TF_KS
+            tt[tid] = (v0 + r < V) ? dT[(long)(v0 + r) * G + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        float acc[TF_ROWS];
+#pragma unroll
+        for (int i = 0; i < TF_ROWS; ++i) acc[i] = 0.f;
+        const int kb = half * (TF_KS / 2);
+#pragma unroll 8
+        for (int kk = kb; kk < kb + TF_KS / 2; ++kk) {
+            const float w = wt[kk * 128 + e_l];
+#pragma unroll
+            for (int i = 0; i < TF_ROWS; ++i) acc[i] = fmaf(tt[i * TF_KS + kk], w, acc[i]);
+        }
+        if (half == 1)
+#pragma unroll
+            for (int i = 0; i < TF_ROWS; ++i) red[i * 128 + e_l] = acc[i];
+        __syncthreads();
+        if (half == 0 && e < E)
+#pragma unroll
+            for (int i = 0; i < TF_ROWS; ++i)
+                if (v0 + i < V) atomicAdd(dEmb + (long)(v0 + i) * E + e, acc[i] + red[i * 128 + e_l]);
+        return;
+    }
+    bid -= nA;
+    if (bid < nB) {                                   // ---- dWx0: 16 gate rows (8 per half) x 128 e, K = V
+        const int et = bid % etiles, g0 = (bid / etiles) * 16;
+        const int e0 = et * 128, e = e0 + e_l;
+        float* tt = sh;                               // dT^T tile [V][16]
+        float* em = sh + 128 * 16;                    // emb tile  [V][128]
+        for (int i = tid; i < V * 16; i += 256) tt[i] = dT[(long)(i >> 4) * G + g0 + (i & 15)];
+        for (int i = tid; i < V * 128; i += 256) {
+            const int v = i >> 7, ee = i & 127;
+            em[i] = (e0 + ee < E) ? emb[(long)v * E + e0 + ee] : 0.f;
+        }
+        __syncthreads();
+        if (e < E) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll 4
+            for (int v = 0; v < V; ++v) {
+                const float x = em[v * 128 + e_l];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(tt[v * 16 + half * 8 + i], x, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dWx0[(long)(g0 + half * 8 + i) * ldw + e] += acc[i];
+        }
+        return;
+    }
+    bid -= nB;
+    const int g = bid * 256 + tid;                    // ---- db0
+    if (g < G) {
+        float a = 0.f;
+        for (int v = 0; v < V; ++v) a += dT[(long)v * G + g];
+        db0[g] += a;
+    }
+}
+
 __global__ void transpose_tokens_kernel(const int32_t* __restrict__ src, int32_t* dst, int B, int T) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B * T) {
@@ -246,6 +339,21 @@ extern "C" int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int 
     if (lds > 64 * 1024) return ARCVAE_ERR_ARG;  // nseg <= 256 (vocabulary-sized segment counts)
     dim3 grid(ceil_div(cols, 64), ceil_div(rows, 256));
     hipLaunchKernelGGL(segsum_kernel, grid, dim3(256), lds + arcvae_side_lds_pad((unsigned)lds), stream, X, seg, rows, nseg, cols, out);
+    return arcvae_launch_status();
+}
+
+// dEmb [V,E] += dT . Wx0[:, :E];  dWx0[:, :E] += dT^T . emb  (row stride ldw >= E);  db0 [4H] += colsum(dT).
+// dT [V,4H] (V <= 128, 4H % 16 == 0).  One launch (see table_finalize_kernel).
+extern "C" int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw, const float* emb, float* dEmb,
+                                     float* dWx0, float* db0, int V, int E, int G, hipStream_t stream) {
+    if (!dT || !Wx0 || !emb || !dEmb || !dWx0 || !db0) return ARCVAE_ERR_ARG;
+    if (V <= 0 || V > 128 || E <= 0 || G <= 0 || (G % 16) != 0 || ldw < E) return ARCVAE_ERR_ARG;
+    if ((G % TF_KS) != 0) return ARCVAE_ERR_ARG;
+    const int etiles = ceil_div(E, 128);
+    const int nA = ceil_div(V, TF_ROWS) * etiles * (G / TF_KS), nB = (G / 16) * etiles, nC = ceil_div(G, 256);
+    const size_t lds = sizeof(float) * (size_t)max(TF_KS * 128 + TF_ROWS * TF_KS + TF_ROWS * 128, 128 * 16 + 128 * 128);
+    hipLaunchKernelGGL(table_finalize_kernel, dim3(nA + nB + nC), dim3(256), lds, stream, dT, Wx0, ldw, emb, dEmb, dWx0,
+                       db0, V, E, G, nA, nB, etiles);
     return arcvae_launch_status();
 }
 

@@ -34,6 +34,9 @@ int arcvae_tile_weights(const float* const* src, float* const* dst, const int* c
                         hipStream_t stream);
 // x[r*ld + c] = 0
 int arcvae_zero(float* x, int rows, int cols, int ld, hipStream_t stream);
+// dEmb += dT . Wx0[:, :E];  dWx0[:, :E] += dT^T . emb;  db0 += colsum(dT)   (dT [V,4H], one launch)
+int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw, const float* emb, float* dEmb, float* dWx0,
+                          float* db0, int V, int E, int G, hipStream_t stream);
 // dst[t*B + b] = src[b*T + t]
 int arcvae_transpose_tokens(const int32_t* src, int32_t* dst, int B, int T, hipStream_t stream);
 }
