@@ -321,7 +321,8 @@ def roofline_probe(eng, ws, torch):
             "us_per_launch": us, "launches_per_sweep": launches,
             "flop_per_launch": flops_total / launches,
             "note": "f32-input MFMA peak (exact-f32 path); the launch is bound by the dependent-chain seam "
-                    "(1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6"}
+                    "(1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6; traffic = "
+                    "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_summary.json (separate --pmc passes)"}
 
 
 if __name__ == "__main__":

@@ -106,6 +106,7 @@ class ARCVAETrainerWithLoss:
         beta = self.compute_beta(epoch)
         tf = self.compute_teacher_forcing_ratio(epoch, total_epochs)
         self.last_train_metrics = self._train_epoch_batches(beta, tf)
+        self.engine.check_gates()  # a device-side gate that expired would mean the step's streams lost their order
         true_train = self._compute_true_train_loss(epoch, num_batches=20)
         val = self._validate(val_dataset, beta) if val_dataset is not None else dict(
             loss=0.0, recon=0.0, kl=0.0, collapse=0.0, prop=0.0)

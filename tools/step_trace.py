@@ -160,7 +160,7 @@ def gated_queue_test(nblocked):
     for it in range(6):
         for o in others:
             with torch.cuda.stream(o):
-                _lib.call("arcvae_gate_wait", _lib.ptr(flag), it + 1, _lib.ptr(err), E.stream_ptr())
+                _lib.call("arcvae_gate_wait", _lib.ptr(flag), None, 0, it + 1, 0, 50_000, _lib.ptr(err), E.stream_ptr())
         eng.enqueue_encoder_forward(ws, run)
         _lib.call("arcvae_gate_set", _lib.ptr(flag), it + 1, 0, E.stream_ptr())
         for o in others:
