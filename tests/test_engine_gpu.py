@@ -177,3 +177,29 @@ def test_unsupported_shapes_are_argument_errors():
         d.update(kw)
         with pytest.raises(ValueError):
             ModelDims(**d).validate()
+
+
+@pytest.mark.parametrize("V,E,Z,C,B,T", [(95, 20, 128, 1, 32, 24), (33, 18, 16, 2, 5, 7), (127, 130, 8, 1, 3, 5)])
+def test_step_odd_vocabulary_and_embedding_sizes(V, E, Z, C, B, T):
+    """Shapes of the reference's own loss test (test_loss_signs.py:19-23: vocab 95, latent 128, batch 32) and sizes
+    that are not multiples of 4 / 16 / 128: vocabulary (one-hot GEMM leading dimension, scalar-load GEMM paths),
+    embedding width (table finalize tiles, E > 128 takes two column tiles), E + C."""
+    cfg = O.Config(vocab_size=V, embedding_dim=E, hidden_dim=64, latent_dim=Z, num_conditions=C, num_layers=2)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+    assert not bad, bad
