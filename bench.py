@@ -291,7 +291,7 @@ def roofline_probe(eng, ws, torch):
     def sweep():
         E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * d.H,
                E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, Tn, d.H, d.L, 0, launches,
-               1, E.stream_ptr())
+               1, None, E.stream_ptr())
 
     sweep()
     torch.cuda.synchronize()

@@ -72,7 +72,8 @@ int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const floa
 int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                              const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dG_t,
                              float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,
-                             int s_end, int retile, arcvae_stream_t stream);
+                             int s_end, int retile, unsigned* start_signal /* optional: += 1 when the first launch of
+                             this call starts (all earlier work of the stream is complete) */, arcvae_stream_t stream);
 /* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,

@@ -152,6 +152,7 @@ class EngineOps:
         base = C.c_void_p(self.bucket_recon.data_ptr() - 4 * (2 * Z + 3))
 
         def fn():
+            eng.gates.join()   # aux and side have reported their last piece of the step
             call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, base, Z, stream_ptr())
         self.run("dp_recon", fn, torch.cuda.current_stream())
 
@@ -180,7 +181,7 @@ class EngineOps:
 
     def backward_local(self) -> None:
         if self.gated:
-            self.eng.enqueue_backward(self.ws, self._grun, gates=self.eng.gates)  # ends with the gate join on R
+            self.eng.enqueue_backward(self.ws, self._grun, gates=self.eng.gates)  # joined in _recon_gated
             return
         self.eng.enqueue_backward(self.ws, self.run)
 

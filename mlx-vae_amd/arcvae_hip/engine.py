@@ -221,6 +221,10 @@ class Gates:
         call("arcvae_gate_wait", self.word(w), self.word(steps), stride, offset, int(advance), self.LONG,
              self.word(self.ERR), stream_ptr())
 
+    def join(self) -> None:
+        """Main-stream gate at the end of a step: aux and side have reported their last piece on R."""
+        self.wait(self.R, self.NM, 2, 2, advance=True)
+
     def errors(self) -> int:
         return int(self.mem[self.ERR * 32].item())
 
@@ -320,11 +324,13 @@ class EncoderBackwardPlan:
              ptr(enc.g("fc_logvar_hidden.weight")), ptr(enc.g("fc_logvar_hidden.bias")),
              ptr(enc.g("fc_logvar.weight")), ptr(enc.g("fc_logvar.bias")), ws.B, d.H, d.Z, d.C, phase, stream_ptr())
 
-    def sweep(self, s0: int, s1: int) -> None:  # d/d(hT) = dcomb[:, :H] (row stride 2H)
+    def sweep(self, s0: int, s1: int, start_signal: Optional[C.c_void_p] = None) -> None:
+        # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
              2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
-             0, stream_ptr())  # retile = 0: the forward of this step already wrote the BPTT weight layouts
+             0,  # retile = 0: the forward of this step already wrote the BPTT weight layouts
+             start_signal if start_signal is not None else C.c_void_p(0), stream_ptr())
 
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3) -> None:
         enc, ws, d = self.enc, self.ws, self.d
@@ -402,15 +408,22 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     if nc + 1 > g.STRIDE:
         raise ValueError("too many BPTT chunks for the gate stride")
     tail_on_side = aux2 is not None and nc >= 2
-    for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
-        def main_seg(c=c, s0=s0, s1=s1, last=last):
-            if c == 0:
-                if prologue:
-                    prologue()
-                plan.heads(1)
-            plan.sweep(s0, s1)
-            g.signal(g.P, g.STRIDE - (1 + c) if last else 1)
 
+    def main_seg():
+        # the whole critical chain of the backward as ONE captured segment: the "chunk c done" signal is raised by
+        # the first launch of chunk c+1 when it starts (no launch of its own, no segment seam); only the last
+        # chunk's signal is a kernel, topping P up to a multiple of STRIDE
+        if prologue:
+            prologue()
+        plan.heads(1)
+        for c, (s0, s1, _t_lo, _t_hi, _first, _last) in enumerate(plan.chunks):
+            plan.sweep(s0, s1, g.word(g.P) if c > 0 else None)
+        g.signal(g.P, g.STRIDE - nc)
+
+    run("main", main_seg, main)
+    if after_first:
+        after_first()
+    for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
         def aux_seg(c=c, t_lo=t_lo, t_hi=t_hi, first=first, last=last):
             g.wait(g.P, g.NA, g.STRIDE, g.STRIDE if last else 2 + c, advance=last)
             if c == 0:
@@ -427,16 +440,13 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             plan.wgrad(t_lo, t_hi, first, last, 2)
             g.signal(g.R, 1)
 
-        run(f"main{c}", main_seg, main)
-        if c == 0 and after_first:
-            after_first()
         if last and tail_on_side:
             run(f"aux2_{c}", side_seg, aux2)
         run(f"aux{c}", aux_seg, aux)
-    # join: main polls R (a gate reacts within ~2 us; an event wait on two other queues cost ~20 us of the tail)
-    run("join", lambda: g.wait(g.R, g.NM, 2, 2, advance=True), main)
     if aux2 is not None and not tail_on_side:
         main.wait_stream(aux2)  # single-chunk sweeps (T <= 3): side only ran the decoder and reported nothing
+    # The caller's next main-stream segment must BEGIN with `Gates.join(g)`: main polls R there (a gate reacts within
+    # ~2 us; an event wait on two other queues cost ~20 us of the exposed tail).
 
 
 def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
@@ -620,13 +630,15 @@ class StepEngine:
         call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z, stream_ptr())
 
     def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline, with_recon: bool = False,
-                       dec_adam: bool = True, join_side: bool = True) -> None:
-        """[CE sum ->] recon/total scalars, join the side stream, both Adam updates: one segment."""
+                       dec_adam: bool = True, join_side: bool = True, gates: Optional[Gates] = None) -> None:
+        """[join ->] [CE sum ->] recon/total scalars, both Adam updates: one segment."""
         main = torch.cuda.current_stream()
         if join_side:
             main.wait_stream(self.side)
 
         def fin():
+            if gates is not None:
+                gates.join()
             if with_recon:
                 self._recon(ws)
             call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
@@ -657,7 +669,7 @@ class StepEngine:
                                  adam_lr=lr if update else None)
             # encoder forward + loss + dcomb + first sweep chunk as ONE segment (no seam between the sweeps)
             self.enqueue_backward(ws, grun, gates=g, fuse_forward=True)
-            self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False)
+            self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False, gates=g)
             return
         self.side.wait_stream(main)                          # the decoder only has to follow the input copies
         self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)

@@ -142,6 +142,8 @@ struct BwdArgs {
     int B, H;
     int prio, remap;
     unsigned long long* trace;
+    unsigned* signal;  // or null: += 1 (agent scope) when this launch STARTS, i.e. when everything before it on the
+                       // stream has completed -- the "sweep chunk done" signal of engine.Gates without a launch of its own
 };
 
 // 16 waves: wave w owns 4H/16 = 16*CH floats of the contraction index.
@@ -151,6 +153,8 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     arcvae_set_prio(a.prio);
     const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     if (tr) a.trace[0] = wall_clock64();
+    if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const BwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
@@ -335,13 +339,16 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
 // (models/encoder.py:106).  Produces dG [L,T,B,4H] (pre-activation gate gradients); weight
 // gradients are formed from dG by arcvae_enc_lstm_wgrad.
 //   dcs, dxs  workspaces [L,T,B,H];  dG_t workspace [L,T,B*4H] (k-chunk-major copy of dG);  wT workspace
-//   [(2L-1),H*4H] (k-chunk-major Wh_l^T, Wx_l^T copies, refreshed when s_begin == 0 and retile != 0).  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
+//   [(2L-1),H*4H] (k-chunk-major Wh_l^T, Wx_l^T copies, refreshed when s_begin == 0 and retile != 0).
+//   start_signal (optional): device word that the FIRST launch of this call bumps by 1 when it starts, i.e. once all
+//   earlier work of the stream (the previous sub-range) is complete: engine.Gates' chunk signal without its own launch.  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
 //   Schedule: cell(l,t) at launch (T-1-t) + 2(L-1-l); xproj_l(t) (dX_l[t] = dG^{l+1}_t . Wx_{l+1}) one launch earlier.
 //   After launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).
 extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                         float* dG_t, float* dcs, float* dxs, float* wT, int B, int T, int H,
-                                        int L, int s_begin, int s_end, int retile, hipStream_t stream) {
+                                        int L, int s_begin, int s_end, int retile, unsigned* start_signal,
+                                        hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
@@ -367,6 +374,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
         a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(g_trace_cap / 2 + s);
+        a.signal = (s == s_begin) ? start_signal : nullptr;
         int nj = 0;
         for (int l = L - 1; l >= 0; --l) {
             const int skew = 2 * (L - 1 - l);

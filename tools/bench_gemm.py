@@ -21,6 +21,17 @@ shapes = [  # name, tA, tB, M, N, K, flags
 ]
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "big":  # BASELINE.json configs[2]: H512 L4 bs 512 (B*V = 40960 decoder rows)
+    shapes = [
+        ("big dWh chunk (TN, K=19968, split)", 1, 0, 2048, 512, 19968, 5),
+        ("big dWh chunk (TN, K=9728, split)", 1, 0, 2048, 512, 9728, 5),
+        ("big dec proj (NT, M=40960)", 0, 1, 40960, 2048, 512, 0),
+        ("big dec dh (NN, M=40960,K=2048)", 0, 0, 40960, 512, 2048, 0),
+        ("big dec dWx (TN, K=40960, split)", 1, 0, 2048, 512, 40960, 5),
+        ("big fc_out (NT, N=80)", 0, 1, 40960, 80, 512, 0),
+    ]
+
+
 def time_one(tA, tB, M, N, K, flags):
     A = torch.randn((K, M) if tA else (M, K), device="cuda")
     B = torch.randn((N, K) if tB else (K, N), device="cuda")
@@ -29,7 +40,7 @@ def time_one(tA, tB, M, N, K, flags):
         _lib.gemm(bool(tA), bool(tB), M, N, K, A, A.shape[1], B, B.shape[1], Cm, N, None, flags)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 50
+    n = 50 if M * N * K < 4e10 else 10
     e0.record()
     for _ in range(n):
         _lib.gemm(bool(tA), bool(tB), M, N, K, A, A.shape[1], B, B.shape[1], Cm, N, None, flags)
