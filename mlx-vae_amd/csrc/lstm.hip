@@ -228,6 +228,253 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int32_t* __restrict__
     }
 }
 
+
+// ---- large-batch step kernels ("tiled") --------------------------------------------------------------------------
+// The 16x16-tile kernels above are built for latency (B = 64: one dependent launch is ~5 us and mostly round trips).
+// Their arithmetic intensity is 4 FLOP per byte pulled from L2, so from a few hundred rows per GPU on they are bound
+// by L2 -> CU delivery (BASELINE.json configs[2], H512 L4 bs 512: 200 / 156 us per forward / BPTT launch = 24 / 31 %
+// of the f32 MFMA peak).  The tiled kernels give every wave a (16*MT rows) x 32 columns register tile over the WHOLE
+// contraction: per 16-wide k-chunk a lane loads MT + 2 float4 fragments straight from the k-chunk-major operand
+// copies (one wave-instruction = 1 KB contiguous) and issues 8*MT MFMAs (v_mfma_f32_16x16x4_f32), i.e. 10.7 (MT=4),
+// 8 (MT=2), 5.3 (MT=1) FLOP per byte, with the next chunk's loads in flight behind the current chunk's MFMAs.  No LDS
+// in the main loop; the 4 waves of a block sit side by side in the column direction and share the A rows through L1.
+template <int MT>
+struct TileFrag {
+    float4 a[MT];
+    float4 w[2];
+};
+
+template <int MT>
+__device__ __forceinline__ void tile_load(TileFrag<MT>& f, const float* __restrict__ At, const int* arow, int RA,
+                                          const float* __restrict__ Wt, const int* wrow, int RW, int kc, int q4) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) f.a[m] = *reinterpret_cast<const float4*>(At + ((long)kc * RA + arow[m]) * 16 + q4);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) f.w[n] = *reinterpret_cast<const float4*>(Wt + ((long)kc * RW + wrow[n]) * 16 + q4);
+}
+
+template <int MT>
+__device__ __forceinline__ void tile_mfma(const TileFrag<MT>& f, f32x4 (&acc)[MT][2]) {
+    // component-major: consecutive MFMAs go to DIFFERENT accumulators, so none waits for its predecessor's result
+#define TILE_MFMA_C(c)                                                                                     \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)           \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[m].c, f.w[n].c, acc[m][n], 0, 0, 0);
+    TILE_MFMA_C(x)
+    TILE_MFMA_C(y)
+    TILE_MFMA_C(z)
+    TILE_MFMA_C(w)
+#undef TILE_MFMA_C
+}
+
+// acc += A[rows, K] . W[cols, K]^T over nch 16-wide chunks (nch % 4 == 0: H is a multiple of 64), operands
+// k-chunk-major.  Four-stage register ring: the loads of chunk kc+3 are issued before the MFMAs of chunk kc, because
+// one chunk's MFMAs (8*MT x 32 cycles) are shorter than an L2 round trip -- with a single chunk in flight the BPTT tile
+// ran 2.8x off its MFMA time (133 us per launch at configs[2] against 48).
+template <int MT>
+__device__ __forceinline__ void tile_contract(f32x4 (&acc)[MT][2], const float* __restrict__ At, const int* arow,
+                                              int RA, const float* __restrict__ Wt, const int* wrow, int RW,
+                                              int nch, int q4) {
+    constexpr int NS = 4;
+    TileFrag<MT> f[NS];
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) tile_load<MT>(f[s], At, arow, RA, Wt, wrow, RW, s, q4);
+    for (int kc0 = 0; kc0 < nch; kc0 += NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int kn = kc0 + s + NS - 1;
+            if (kn < nch) tile_load<MT>(f[(s + NS - 1) % NS], At, arow, RA, Wt, wrow, RW, kn, q4);
+            tile_mfma<MT>(f[s], acc);
+        }
+    }
+}
+
+// Forward: block = 16*MT rows x 128 gate columns (32 hidden units; wave w owns units [8w, 8w+8) of them).
+// grid (H/32, ceil(B / (16*MT)), jobs).  The pre-activations go through a per-wave LDS tile so that one lane gets
+// the four gates of one (row, unit); then the same fused cell update as lstm_fwd_step_kernel.
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
+    const FwdJob& j = a.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H, G = 4 * a.H;
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    const int row0 = blockIdx.y * 16 * MT;
+    const int wcol0 = blockIdx.x * 128 + wave * 32;  // permuted weight rows: 16 consecutive = 4 units x (i,f,g,o)
+    const int ubase = blockIdx.x * 32 + wave * 8;    // first hidden unit of this wave
+    int arow[MT], wrow[2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) arow[m] = min(row0 + 16 * m + r, B - 1);
+    wrow[0] = wcol0 + r;
+    wrow[1] = wcol0 + 16 + r;
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nch = H >> 4;
+    if (j.xin) tile_contract<MT>(acc, j.xin, arow, B, j.Wx, wrow, G, nch, q4);
+    if (j.hprev) tile_contract<MT>(acc, j.hprev, arow, B, j.Wh, wrow, G, nch, q4);
+    // accumulators -> per-wave LDS tile [16*MT][33]: D[row = 4*(lane>>4) + reg][col = lane & 15]
+    float* t = lds + wave * (16 * MT * 33);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) t[(16 * m + (lane >> 4) * 4 + reg) * 33 + 16 * n + r] = acc[m][n][reg];
+    __syncthreads();
+    // (row, unit) pairs of the wave: 16*MT rows x 8 units, 2*MT per lane.  All loads of all pairs are issued before
+    // the first store: the output pointers may alias the inputs as far as the compiler knows, so a load placed after a
+    // store would wait for it, and the token -> table-row -> cell chain would be paid 2*MT times in sequence.
+    constexpr int NP = 2 * MT;
+    int prow[NP], punit[NP];
+    long poff[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const int idx = it * 64 + lane;
+        prow[it] = row0 + (idx >> 3);
+        punit[it] = ubase + (idx & 7);
+        const int rc = min(prow[it], B - 1);
+        long o = 0;
+        if (j.tok) {
+            int tk = j.tok[rc];
+            tk = min(max(tk, 0), a.V - 1);
+            o = (long)tk * G;
+        }
+        poff[it] = o;
+    }
+    float pv[NP][4], cpv[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const float* pre = j.pre + poff[it] + punit[it];
+        pv[it][0] = pre[0]; pv[it][1] = pre[H]; pv[it][2] = pre[2 * H]; pv[it][3] = pre[3 * H];
+        cpv[it] = j.cprev ? j.cprev[(long)min(prow[it], B - 1) * H + punit[it]] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const int idx = it * 64 + lane;
+        const int rl = idx >> 3, ul = idx & 7;
+        const int row = prow[it], unit = punit[it];
+        if (row >= B) continue;
+        const float* tp = t + rl * 33 + 16 * (ul >> 2) + (ul & 3);
+        const float gi = sigmoidf_acc(tp[0] + pv[it][0]);
+        const float gf = sigmoidf_acc(tp[4] + pv[it][1]);
+        const float gg = tanhf(tp[8] + pv[it][2]);
+        const float go = sigmoidf_acc(tp[12] + pv[it][3]);
+        const long hb = (long)row * H + unit;
+        const float c = j.cprev ? gf * cpv[it] + gi * gg : gi * gg;
+        const float hv = go * tanhf(c);
+        float* gp = j.gates + (long)row * G + unit;
+        gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+        j.h[hb] = hv;
+        j.ht[((long)(unit >> 4) * B + row) * 16 + (unit & 15)] = hv;
+        j.c[hb] = c;
+    }
+    if (tr) a.trace[1] = wall_clock64();
+}
+
+// BPTT: block = 16*MT rows x 128 hidden units (wave w: units [32w, 32w+32)), K = 4H.  grid (ceil(H/128),
+// ceil(B / (16*MT)), jobs).  An accumulator element IS one (row, unit): the cell epilogue runs on the registers.
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
+    if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const BwdJob& j = a.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H, G = 4 * a.H;
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    const int row0 = blockIdx.y * 16 * MT;
+    const int u0 = blockIdx.x * 128 + wave * 32;
+    if (u0 >= H) return;                              // H not a multiple of 128: this wave has no units
+    int arow[MT], wrow[2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) arow[m] = min(row0 + 16 * m + r, B - 1);
+    wrow[0] = min(u0 + r, H - 1);
+    wrow[1] = min(u0 + 16 + r, H - 1);
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j.src) tile_contract<MT>(acc, j.src, arow, B, j.WT, wrow, H, G >> 4, q4);
+    const bool cell = j.kind == 0;
+    // Epilogue per 16-row group m: the 8 (row, unit) elements of a lane are loaded together (clamped indices, no
+    // branch between the loads) and only then computed and stored -- see the forward tile kernel.
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float gi[8], gf[8], gg[8], go[8], cv[8], cpv[8], dci[8], exv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = e >> 2, reg = e & 3;
+            const int unit = min(u0 + 16 * n + r, H - 1);
+            const int row = min(row0 + 16 * m + (lane >> 4) * 4 + reg, B - 1);
+            const long hb = (long)row * H + unit;
+            exv[e] = j.ext ? j.ext[(long)row * j.ext_ld + unit] : 0.f;
+            if (cell) {
+                const float* gp = j.gates + (long)row * G + unit;
+                gi[e] = gp[0]; gf[e] = gp[H]; gg[e] = gp[2 * H]; go[e] = gp[3 * H];
+                cv[e] = j.c[hb];
+                cpv[e] = j.cprev ? j.cprev[hb] : 0.f;
+                dci[e] = j.dcin ? j.dcin[hb] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = e >> 2, reg = e & 3;
+            const int unit = u0 + 16 * n + r;
+            const int row = row0 + 16 * m + (lane >> 4) * 4 + reg;
+            if (unit >= H || row >= B) continue;
+            const long hb = (long)row * H + unit;
+            const float dh = acc[m][n][reg] + exv[e];
+            if (!cell) {
+                j.out[hb] = dh;
+                continue;
+            }
+            const float i = gi[e], f = gf[e], g = gg[e], o = go[e];
+            const float tc = tanhf(cv[e]);
+            const float d_o = dh * tc * o * (1.f - o);
+            const float dc = dh * o * (1.f - tc * tc) + dci[e];
+            const float d_i = dc * g * i * (1.f - i);
+            const float d_f = j.cprev ? dc * cpv[e] * f * (1.f - f) : 0.f;
+            const float d_g = dc * i * (1.f - g * g);
+            j.dcout[hb] = dc * f;
+            float* dp = j.out + (long)row * G + unit;
+            dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+            float* tp = j.outt + ((long)(unit >> 4) * B + row) * 16 + (unit & 15);
+            const long gs = (long)(H >> 4) * B * 16;
+            tp[0] = d_i; tp[gs] = d_f; tp[2 * gs] = d_g; tp[3 * gs] = d_o;
+        }
+    }
+    if (tr) a.trace[1] = wall_clock64();
+}
+
+// Largest register tile whose grid still fills the chip (>= 200 blocks), or 0 = keep the latency-oriented 16x16
+// kernels.  ARCVAE_STEP_TILE: -1 auto (default), 0 never, 1 / 2 / 4 force that MT.
+inline int choose_tile_mt(int B, int col_blocks, int jobs) {
+    const int force = arcvae_env_int("ARCVAE_STEP_TILE", -1);  // read per sweep call (tests toggle it)
+    if (force == 0) return 0;
+    if (force == 1 || force == 2 || force == 4) return force;
+    const int mts[2] = {4, 2};  // MT = 1 never pays: at that size the all-loads-first 16x16 kernels are ahead
+    for (int i = 0; i < 2; ++i)
+        if (ceil_div(B, 16 * mts[i]) * col_blocks * jobs >= 200) return mts[i];
+    return 0;
+}
+
+template <int MT>
+void launch_fwd_tile(const FwdArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_fwd_tile_kernel<MT>, grid, dim3(256), 4 * 16 * MT * 33 * sizeof(float), s, a);
+}
+template <int MT>
+void launch_bwd_tile(const BwdArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_bwd_tile_kernel<MT>, grid, dim3(256), 0, s, a);
+}
+
 template <int CH>
 void launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(lstm_fwd_step_kernel<CH>, grid, dim3(256), 0, s, a);
@@ -308,6 +555,7 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             if (rc != ARCVAE_OK) return rc;
         }
     }
+    const int tile_mt = choose_tile_mt(B, H / 32, L);
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
         a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(s);
@@ -329,6 +577,13 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             j.gates = gseq + l * lG + t * sG;
         }
         for (int k = nj; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
+        if (tile_mt) {
+            dim3 tgrid(H / 32, ceil_div(B, 16 * tile_mt), nj);
+            if (tile_mt == 4) launch_fwd_tile<4>(a, tgrid, stream);
+            else if (tile_mt == 2) launch_fwd_tile<2>(a, tgrid, stream);
+            else launch_fwd_tile<1>(a, tgrid, stream);
+            continue;
+        }
         dim3 grid(H / 4, ceil_div(B, 16), nj);
         DISPATCH_CH(H, launch_fwd, a, grid, stream)
     }
@@ -371,6 +626,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
     }
+    const int tile_mt = choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1);
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
         a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(g_trace_cap / 2 + s);
@@ -409,6 +665,13 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         }
         if (nj == 0) continue;
         for (int k = nj; k < ARCVAE_MAX_BWD_JOBS; ++k) a.job[k] = a.job[0];
+        if (tile_mt) {
+            dim3 tgrid(ceil_div(H, 128), ceil_div(B, 16 * tile_mt), nj);
+            if (tile_mt == 4) launch_bwd_tile<4>(a, tgrid, stream);
+            else if (tile_mt == 2) launch_bwd_tile<2>(a, tgrid, stream);
+            else launch_bwd_tile<1>(a, tgrid, stream);
+            continue;
+        }
         dim3 grid(H / 16, ceil_div(B, 16), nj);
         DISPATCH_CH(H, launch_bwd, a, grid, stream)
     }

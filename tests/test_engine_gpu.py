@@ -203,3 +203,33 @@ def test_step_odd_vocabulary_and_embedding_sizes(V, E, Z, C, B, T):
         elif rel_err(got, g) >= TOL:
             bad[name] = rel_err(got, g)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("mt", [1, 2, 4])
+@pytest.mark.parametrize("H,L,B,T,C", [(64, 2, 37, 6, 1), (192, 3, 70, 5, 2), (128, 1, 16, 4, 1), (256, 2, 130, 4, 1)])
+def test_tiled_large_batch_step_kernels(mt, H, L, B, T, C, monkeypatch):
+    """The register-tiled step kernels (lstm_fwd_tile_kernel / lstm_bwd_tile_kernel: the large-batch path,
+    BASELINE.json configs[2]) forced on at small shapes: ragged row tiles, H not a multiple of 128 (idle waves in
+    the BPTT tile), single layer, every MT.  Same bar as the latency kernels: 1e-4 against the fp64 oracle."""
+    monkeypatch.setenv("ARCVAE_STEP_TILE", str(mt))
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    for k in ("mu", "logvar"):
+        assert rel_err(out[k].cpu().numpy(), vals[k]) < TOL, k
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+    assert not bad, bad
