@@ -60,7 +60,8 @@ int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A,
  * x_tb [T,B] int32 tokens (time-major; arcvae_transpose_tokens makes it from [B,T]);
  * table0 [V,4H] = embedding . Wx_0^T + bias_0 (one arcvae_gemm_f32 call);
  * outputs hseq,cseq [L,T,B,H], gseq [L,T,B,4H] (post-activation gates, saved for BPTT);
- * workspaces hseq_t [L,T,B*H] and wt [(2L-1),4H*H]: k-chunk-major operand copies for the step kernels. */
+ * workspaces hseq_t [L,RS,B*H] (ring over t, RS = min(T,16) slots; a [L,T,B*H] buffer is always large enough) and wt [(2L-1),4H*H]: k-chunk-major operand copies for the
+ * step kernels. */
 int arcvae_transpose_tokens(const int32_t* src_bt, int32_t* dst_tb, int B, int T, arcvae_stream_t stream);
 int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                             const float* const* Wh, const float* const* bias, float* hseq, float* hseq_t,
@@ -68,7 +69,8 @@ int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const floa
                             int H, int L, arcvae_stream_t stream);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
- * position read by models/encoder.py:106.  dG out [L,T,B,4H]; dG_t ws [L,T,B*4H]; dcs, dxs ws [L,T,B,H]; wT ws [(2L-1),H*4H]. */
+ * position read by models/encoder.py:106.  dG out [L,T,B,4H] (may alias gseq: in-place); dG_t ws [L,RS,B*4H]; dcs, dxs
+ * ws [L,RS,B,H] (rings over t with RS = min(T,16) slots: a slab is consumed by the next launch only); wT ws [(2L-1),H*4H]. */
 int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                              const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dG_t,
                              float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,

@@ -75,7 +75,9 @@ class Workspace:
         # encoder forward
         self.table0 = torch.empty(V, G, **f32)
         self.hseq = torch.empty(L, T, B, H, **f32)
-        self.hseq_t = torch.empty(L, T, B * H, **f32)      # k-chunk-major copy (step-kernel operand layout)
+        RS = int(os.environ.get("ARCVAE_RING", "16"))  # ring slots over t (csrc/common.h: arcvae_ring_slots)
+        RS = T if (RS <= 0 or RS > T) else RS
+        self.hseq_t = torch.empty(L, RS, B * H, **f32)     # k-chunk-major copy of h_t in slot t % RS (next launch's operand)
         self.wt = torch.empty(2 * L - 1, G * H, **f32)        # k-chunk-major weights (forward layout)
         self.cseq = torch.empty(L, T, B, H, **f32)
         self.gseq = torch.empty(L, T, B, G, **f32)
@@ -102,10 +104,13 @@ class Workspace:
             self.dlv_raw = torch.empty(B, Z, **f32)
             self.dlh = torch.empty(B, 2 * H, **f32)
             self.dcomb = torch.empty(B, 2 * H, **f32)
-            self.dG = torch.empty(L, T, B, G, **f32)
-            self.dG_t = torch.empty(L, T, B * G, **f32)       # k-chunk-major copy
-            self.dcs = torch.empty(L, T, B, H, **f32)
-            self.dxs = torch.empty(L, T, B, H, **f32)
+            # Working set of a step: 390 -> 215 MB, i.e. inside the 256 MB Infinity Cache.  The gate gradients are
+            # written IN PLACE over the saved gates (same thread, after it has read them), and everything only the
+            # next BPTT launch consumes lives in short rings over t (csrc/lstm.hip, common.h: arcvae_ring_slots).
+            self.dG = self.gseq if os.environ.get("ARCVAE_INPLACE_DG", "1") != "0" else torch.empty(L, T, B, G, **f32)
+            self.dG_t = torch.empty(L, RS, B * G, **f32)      # k-chunk-major copy of dG_t in slot t % RS
+            self.dcs = torch.empty(L, RS, B, H, **f32)
+            self.dxs = torch.empty(L, RS, B, H, **f32)
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
             self.dtable0 = torch.empty(V, G, **f32)
             self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)

@@ -37,6 +37,14 @@ static inline int arcvae_step_prio() {
     static const int v = arcvae_env_int("ARCVAE_STEP_PRIO", 3);
     return v < 0 ? 0 : (v > 3 ? 3 : v);
 }
+// Slots of the per-layer rings over t (k-chunk-major operand copies, dc and dX slabs): a slab is produced by one launch
+// and consumed by the next only, so a short ring keeps them cache-resident instead of streaming [L,T,..] buffers
+// through the Infinity Cache.  16, not 2: re-writing a line two launches after other XCDs read it costs +0.3 us per
+// BPTT launch (measured: 2-4 slots 5.3 us, >= 8 slots 5.05 us; whole step 1.58 / 1.55 ms).  ARCVAE_RING=0: T slots.
+static inline int arcvae_ring_slots(int T) {
+    const int v = arcvae_env_int("ARCVAE_RING", 16);
+    return (v <= 0 || v > T) ? T : v;
+}
 static inline int arcvae_xcd_remap() {
     static const int v = arcvae_env_int("ARCVAE_XCD_REMAP", 1);
     return v != 0;

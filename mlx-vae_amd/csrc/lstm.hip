@@ -521,7 +521,10 @@ extern "C" int arcvae_set_step_trace(unsigned long long* buf, int cap) {
 //   x_tb   [T,B] tokens (time-major)          table0 [V,4H] = emb . Wx_0^T + bias_0
 //   Wx[l]  [4H,H] (l >= 1), Wh[l] [4H,H], bias[l] [4H] (l >= 1): HOST arrays of device pointers
 //   hseq/cseq [L,T,B,H], gseq [L,T,B,4H] outputs (gseq = post-activation i,f,g,o)
-//   hseq_t [L,T,B*H] workspace: k-chunk-major copy of every h slab (operand layout of the step kernels)
+//   hseq_t [L,RS,B*H] workspace: k-chunk-major copy of the h slab of time t in slot t % RS, RS = min(T, 16)
+//          (common.h: arcvae_ring_slots).  A slab is only read by the NEXT launch (same layer at t+1, layer above at
+//          t), so a short ring suffices and stays cache-resident, unlike a [L,T,..] copy that streams 17 MB through
+//          the Infinity Cache
 //   wt     [(2L-1),4H*H] workspace: k-chunk-major weight copies, refreshed here (weights change every step)
 //   wT_bwd optional [(2L-1),H*4H]: also write the BPTT layouts (then call the backward with retile = 0)
 //   hidden_dim: multiple of 64, <= 512.
@@ -556,6 +559,7 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
         }
     }
     const int tile_mt = choose_tile_mt(B, H / 32, L);
+    const int RS = arcvae_ring_slots(T);
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
         a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(s);
@@ -564,15 +568,15 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             const int t = s - l;
             if (t < 0 || t >= T) continue;
             FwdJob& j = a.job[nj++];
-            j.xin = l > 0 ? hseq_t + (l - 1) * lH + t * sH : nullptr;
+            j.xin = l > 0 ? hseq_t + ((long)(l - 1) * RS + (t % RS)) * sH : nullptr;
             j.Wx = l > 0 ? wt + (L + l - 1) * wsz : nullptr;
-            j.hprev = t > 0 ? hseq_t + l * lH + (t - 1) * sH : nullptr;
+            j.hprev = t > 0 ? hseq_t + ((long)l * RS + ((t - 1) % RS)) * sH : nullptr;
             j.Wh = wt + l * wsz;
             j.pre = l > 0 ? bias[l] : table0;
             j.tok = l > 0 ? nullptr : x_tb + (long)t * B;
             j.cprev = t > 0 ? cseq + l * lH + (t - 1) * sH : nullptr;
             j.h = hseq + l * lH + t * sH;
-            j.ht = hseq_t + l * lH + t * sH;
+            j.ht = hseq_t + ((long)l * RS + (t % RS)) * sH;
             j.c = cseq + l * lH + t * sH;
             j.gates = gseq + l * lG + t * sG;
         }
@@ -593,7 +597,9 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
 // BPTT for the stack.  Only h_{T-1} of the top layer receives an external gradient
 // (models/encoder.py:106).  Produces dG [L,T,B,4H] (pre-activation gate gradients); weight
 // gradients are formed from dG by arcvae_enc_lstm_wgrad.
-//   dcs, dxs  workspaces [L,T,B,H];  dG_t workspace [L,T,B*4H] (k-chunk-major copy of dG);  wT workspace
+//   dcs, dxs  workspaces [L,RS,B,H];  dG_t workspace [L,RS,B*4H] (k-chunk-major copy of dG): rings indexed by t % RS,
+//   RS = min(T, 16) -- each slab is produced by one launch and consumed by the next only.  dG may alias gseq (the gate
+//   gradients of (l,t) then overwrite the saved gates of (l,t), which the same thread has just read);  wT workspace
 //   [(2L-1),H*4H] (k-chunk-major Wh_l^T, Wx_l^T copies, refreshed when s_begin == 0 and retile != 0).
 //   start_signal (optional): device word that the FIRST launch of this call bumps by 1 when it starts, i.e. once all
 //   earlier work of the stream (the previous sub-range) is complete: engine.Gates' chunk signal without its own launch.  The sweep is T + 2(L-1) dependent launches; [s_begin, s_end) selects a sub-range.
@@ -627,6 +633,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         if (rc != ARCVAE_OK) return rc;
     }
     const int tile_mt = choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1);
+    const int RS = arcvae_ring_slots(T);
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
         a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(g_trace_cap / 2 + s);
@@ -639,27 +646,27 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 BwdJob& j = a.job[nj++];
                 const bool top = (l == L - 1), last = (t == T - 1);
                 j.kind = 0;
-                j.src = last ? nullptr : dG_t + l * lG + (t + 1) * sG;
+                j.src = last ? nullptr : dG_t + ((long)l * RS + ((t + 1) % RS)) * sG;
                 j.WT = wT + l * wsz;
                 if (top) { j.ext = last ? dh_top : nullptr; j.ext_ld = ld_dh_top; }
-                else { j.ext = dxs + l * lH + t * sH; j.ext_ld = H; }
+                else { j.ext = dxs + ((long)l * RS + (t % RS)) * sH; j.ext_ld = H; }
                 j.gates = gseq + l * lG + t * sG;
                 j.c = cseq + l * lH + t * sH;
                 j.cprev = t > 0 ? cseq + l * lH + (t - 1) * sH : nullptr;
-                j.dcin = last ? nullptr : dcs + l * lH + (t + 1) * sH;
-                j.dcout = dcs + l * lH + t * sH;
+                j.dcin = last ? nullptr : dcs + ((long)l * RS + ((t + 1) % RS)) * sH;
+                j.dcout = dcs + ((long)l * RS + (t % RS)) * sH;
                 j.out = dG + l * lG + t * sG;
-                j.outt = dG_t + l * lG + t * sG;
+                j.outt = dG_t + ((long)l * RS + (t % RS)) * sG;
             }
             const int tx = T - 1 - (s + 1 - skew);     // xproj_l(tx): feeds cell(l, tx) at the next launch
             if (l < L - 1 && tx >= 0 && tx < T) {
                 BwdJob& j = a.job[nj++];
                 j.kind = 1;
-                j.src = dG_t + (l + 1) * lG + tx * sG;
+                j.src = dG_t + ((long)(l + 1) * RS + (tx % RS)) * sG;
                 j.WT = wT + (L + l) * wsz;             // WxT[l+1]
                 j.ext = nullptr; j.ext_ld = H;
                 j.gates = nullptr; j.c = nullptr; j.cprev = nullptr; j.dcin = nullptr; j.dcout = nullptr;
-                j.out = dxs + l * lH + tx * sH;
+                j.out = dxs + ((long)l * RS + (tx % RS)) * sH;
                 j.outt = nullptr;
             }
         }
