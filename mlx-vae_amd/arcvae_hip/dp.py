@@ -105,7 +105,18 @@ class EngineOps:
         Z = engine.d.Z
         self.stats = ws.stats[:2 * Z + 3]
         self.run = engine.runner(ws, lr, global_rows, capture=use_graph)
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            # warm the communicator up (channel / IPC set-up of the first collective can take seconds on 8 GPUs) before
+            # any gate kernel can be left spinning behind it
+            warm = torch.zeros(1024, dtype=torch.float32, device=engine.device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
         self.gated = engine.mode != "graph" and engine._gating_ok(torch.cuda.current_stream())
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            # the two forms issue different collective sequences: every rank must take the same one
+            flag = torch.tensor([1.0 if self.gated else 0.0], device=engine.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            self.gated = bool(flag.item() > 0.5)
         if self.gated:
             self._make_bucket()
             self.recon_stat = None

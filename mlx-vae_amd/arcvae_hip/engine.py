@@ -209,7 +209,8 @@ class Gates:
     side / aux / main (the waiter's own ticket counter), ERR expired gates, PROBE self-test.
     """
     STRIDE = 8
-    LONG, SHORT = 4_000_000, 3_000     # polls (~1 us each): ~4 s before a gate gives up; ~3 ms for the probe
+    LONG, SHORT = 16_000_000, 3_000    # polls (~1.5 us each): ~25 s before a gate gives up (a first RCCL collective
+                                       # or a peer still capturing its graphs may hold main up for seconds); ~4 ms probe
     P, Q, NS, NA, ERR, PROBE, R, NM = range(8)
 
     def __init__(self, device):
