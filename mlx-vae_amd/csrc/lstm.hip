@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
 // kernels.  ARCVAE_STEP_TILE: -1 auto (default), 0 never, 1 / 2 / 4 force that MT.
 inline int choose_tile_mt(int B, int col_blocks, int jobs) {
     const int force = arcvae_env_int("ARCVAE_STEP_TILE", -1);  // read per sweep call (tests toggle it)
-    if (force == 0) return 0;
+    if (force == 0 || force == 22) return 0;
     if (force == 1 || force == 2 || force == 4) return force;
     const int mts[2] = {4, 2};  // MT = 1 never pays: at that size the all-loads-first 16x16 kernels are ahead
     for (int i = 0; i < 2; ++i)
@@ -473,6 +473,121 @@ void launch_fwd_tile(const FwdArgs& a, dim3 grid, hipStream_t s) {
 template <int MT>
 void launch_bwd_tile(const BwdArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(lstm_bwd_tile_kernel<MT>, grid, dim3(256), 0, s, a);
+}
+
+
+// ---- mid-batch BPTT step kernel ("2x2") ---------------------------------------------------------------------------
+// Between the latency regime (B = 64) and the register-tiled one (grids of >= 200 blocks) -- per-GPU batches of
+// 256..512 rows, e.g. the 256 rows per GPU of BASELINE.json configs[3] -- the 16x16 kernel is bound by L2 -> CU
+// delivery (each block pulls 64 KB of A and 64 KB of W for a 16x16 tile: 98 MB per launch at B = 256) while the
+// tiled kernel's grid is too small.  This kernel keeps the latency kernel's shape (K = 4H split over 16 waves, every
+// load issued before the first MFMA, epilogue operands requested first) but gives each wave 2 x 2 fragments: a block
+// covers 32 rows x 32 hidden units, i.e. half the bytes per output, and its 1024 threads each own exactly one
+// (row, unit) of the epilogue.  Measured (MI355X, H256 L2): the launch itself barely moves (10.8 -> 10.7 us at bs 256,
+// 17.9 -> 17.0 at bs 512: its 192..384 blocks are MFMA-serialised, 16 waves on 4 SIMDs), the step does (4.02 -> 3.87 ms
+// and 7.35 -> 6.70 ms) because the sweep takes half the L2 bandwidth away from the GEMMs beside it; at bs 128 it loses
+// (6.9 -> 9.5 us), hence the threshold.  A 2-D XCD partition of the blocks (A/p + W/q fabric bytes per XCD instead of
+// all of A) was tried on top and changed nothing: the launch is not fabric-bound.
+template <int CH>
+__global__ __launch_bounds__(1024) void lstm_bwd_step2_kernel(BwdArgs a) {
+    __shared__ float red[16 * 1024];  // [wave][32 rows][32 units]
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
+    if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const BwdJob& j = a.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H, G = 4 * a.H;
+    const int r0 = blockIdx.y * 32, u0 = blockIdx.x * 32;
+    const bool cell = j.kind == 0;
+    // epilogue role: thread -> (row = tid >> 5, unit = tid & 31); operands requested first
+    const int erow = tid >> 5, ecol = tid & 31;
+    const int eb = min(r0 + erow, B - 1);
+    const int unit = min(u0 + ecol, H - 1);
+    const long hb = (long)eb * H + unit;
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c_v = 0.f, cprev_v = 0.f, dcin_v = 0.f, ext_v = 0.f;
+    if (j.ext) ext_v = j.ext[(long)eb * j.ext_ld + unit];
+    if (cell) {
+        const float* gp = j.gates + (long)eb * G + unit;
+        gi = gp[0]; gf = gp[H]; gg = gp[2 * H]; go = gp[3 * H];
+        c_v = j.c[hb];
+        if (j.cprev) cprev_v = j.cprev[hb];
+        if (j.dcin) dcin_v = j.dcin[hb];
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j.src) {
+        const int r = lane & 15, q4 = (lane >> 4) * 4;
+        const int arow0 = min(r0 + r, B - 1), arow1 = min(r0 + 16 + r, B - 1);
+        const int wrow0 = min(u0 + r, H - 1), wrow1 = min(u0 + 16 + r, H - 1);
+        float4 fa[2][CH], fw[2][CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {   // wave w owns chunks [w*CH, (w+1)*CH) of the 4H/16 chunks
+            const long kc = wave * CH + c;
+            fa[0][c] = *reinterpret_cast<const float4*>(j.src + (kc * B + arow0) * 16 + q4);
+            fa[1][c] = *reinterpret_cast<const float4*>(j.src + (kc * B + arow1) * 16 + q4);
+            fw[0][c] = *reinterpret_cast<const float4*>(j.WT + (kc * H + wrow0) * 16 + q4);
+            fw[1][c] = *reinterpret_cast<const float4*>(j.WT + (kc * H + wrow1) * 16 + q4);
+        }
+#define STEP2_MFMA(comp)                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)               \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][c].comp, fw[n][c].comp, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            STEP2_MFMA(x) STEP2_MFMA(y) STEP2_MFMA(z) STEP2_MFMA(w)
+        }
+#undef STEP2_MFMA
+    }
+    {   // partial tiles -> red[wave][row][unit]: D[row = 4*(lane>>4) + reg][col = lane & 15] per 16x16 fragment
+        float* p = red + wave * 1024;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    p[(16 * m + (lane >> 4) * 4 + reg) * 32 + 16 * n + (lane & 15)] = acc[m][n][reg];
+    }
+    __syncthreads();
+    if (r0 + erow < B && u0 + ecol < H) {
+        float dh = ext_v;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) dh += red[w * 1024 + erow * 32 + ecol];
+        if (!cell) {
+            j.out[hb] = dh;
+        } else {
+            const float i = gi, f = gf, g = gg, o = go;
+            const float tc = tanhf(c_v);
+            const float d_o = dh * tc * o * (1.f - o);
+            const float dc = dh * o * (1.f - tc * tc) + dcin_v;
+            const float d_i = dc * g * i * (1.f - i);
+            const float d_f = j.cprev ? dc * cprev_v * f * (1.f - f) : 0.f;
+            const float d_g = dc * i * (1.f - g * g);
+            j.dcout[hb] = dc * f;
+            float* dp = j.out + (long)eb * G + unit;
+            dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+            float* tp = j.outt + ((long)(unit >> 4) * B + eb) * 16 + (unit & 15);
+            const long gs = (long)(H >> 4) * B * 16;
+            tp[0] = d_i; tp[gs] = d_f; tp[2 * gs] = d_g; tp[3 * gs] = d_o;
+        }
+    }
+    if (tr) a.trace[1] = wall_clock64();
+}
+template <int CH>
+void launch_bwd2(const BwdArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_bwd_step2_kernel<CH>, grid, dim3(1024), 0, s, a);
+}
+// Mid-batch kernels when the batch is >= 256 rows (and the tiled form was not chosen).  ARCVAE_STEP_TILE=22 forces
+// them, 0 disables them together with the tiled kernels.
+inline bool choose_step2(int B) {
+    const int force = arcvae_env_int("ARCVAE_STEP_TILE", -1);
+    if (force == 22) return true;
+    if (force >= 0) return false;
+    return B >= 256;
 }
 
 template <int CH>
@@ -633,6 +748,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         if (rc != ARCVAE_OK) return rc;
     }
     const int tile_mt = choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1);
+    const bool step2 = !tile_mt && choose_step2(B);
     const int RS = arcvae_ring_slots(T);
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
@@ -677,6 +793,11 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
             if (tile_mt == 4) launch_bwd_tile<4>(a, tgrid, stream);
             else if (tile_mt == 2) launch_bwd_tile<2>(a, tgrid, stream);
             else launch_bwd_tile<1>(a, tgrid, stream);
+            continue;
+        }
+        if (step2) {
+            dim3 grid2(ceil_div(H, 32), ceil_div(B, 32), nj);
+            DISPATCH_CH(H, launch_bwd2, a, grid2, stream)
             continue;
         }
         dim3 grid(H / 16, ceil_div(B, 16), nj);
