@@ -2,16 +2,18 @@
 
 Reference path: trainer.py:303-333 -> complete_vae_loss.py:37-99 ->
 models/encoder.py:76-155, models/decoder.py:113-190, losses/{recon,kl,info}.py, then two
-MLX Adam updates.  Here the same step is a fixed sequence of launches on two HIP streams:
+MLX Adam updates.  Here the same step is a fixed sequence of launches on three HIP streams:
 
   main stream : tokens^T -> table0 GEMM -> LSTM wavefront sweep -> heads -> [stats seam]
-                -> latent loss -> heads dcomb chain -> BPTT wavefront -> Adam
-  side stream : dense decoder fwd (B*V rows) -> TF walk + CE -> dlogits -> dense decoder bwd
+                -> latent loss -> heads dcomb chain -> BPTT wavefront -> join -> Adam      (the dependent chain)
+  side stream : dense decoder fwd (B*V rows) -> TF walk + CE -> dlogits -> dense decoder bwd -> its Adam;
+                at the end the token-table half of the last weight-gradient chunk
   aux stream  : parameter-gradient GEMMs of the encoder, chunk by chunk behind the BPTT sweep
 
 The decoder never reads z, so the streams only meet at the loss scalars.  Each
 stream's launch sequence is captured once per (B,T) shape into linear hipGraph segments and
-replayed; inputs, teacher-forcing coins and the epoch-scheduled hyper-parameters live in static
+replayed; the streams are ordered among each other by device-side gates (class Gates), not by
+events; inputs, teacher-forcing coins and the epoch-scheduled hyper-parameters live in static
 device buffers.
 
 Nothing here computes on the CPU and nothing falls back to PyTorch ops for the math: torch is
