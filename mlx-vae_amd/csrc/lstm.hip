@@ -238,26 +238,26 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int32_t* __restrict__
 // copies (one wave-instruction = 1 KB contiguous) and issues 8*MT MFMAs (v_mfma_f32_16x16x4_f32), i.e. 10.7 (MT=4),
 // 8 (MT=2), 5.3 (MT=1) FLOP per byte, with the next chunk's loads in flight behind the current chunk's MFMAs.  No LDS
 // in the main loop; the 4 waves of a block sit side by side in the column direction and share the A rows through L1.
-template <int MT>
+template <int MT, int NT>
 struct TileFrag {
     float4 a[MT];
-    float4 w[2];
+    float4 w[NT];
 };
 
-template <int MT>
-__device__ __forceinline__ void tile_load(TileFrag<MT>& f, const float* __restrict__ At, const int* arow, int RA,
+template <int MT, int NT>
+__device__ __forceinline__ void tile_load(TileFrag<MT, NT>& f, const float* __restrict__ At, const int* arow, int RA,
                                           const float* __restrict__ Wt, const int* wrow, int RW, int kc, int q4) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) f.a[m] = *reinterpret_cast<const float4*>(At + ((long)kc * RA + arow[m]) * 16 + q4);
 #pragma unroll
-    for (int n = 0; n < 2; ++n) f.w[n] = *reinterpret_cast<const float4*>(Wt + ((long)kc * RW + wrow[n]) * 16 + q4);
+    for (int n = 0; n < NT; ++n) f.w[n] = *reinterpret_cast<const float4*>(Wt + ((long)kc * RW + wrow[n]) * 16 + q4);
 }
 
-template <int MT>
-__device__ __forceinline__ void tile_mfma(const TileFrag<MT>& f, f32x4 (&acc)[MT][2]) {
+template <int MT, int NT>
+__device__ __forceinline__ void tile_mfma(const TileFrag<MT, NT>& f, f32x4 (&acc)[MT][NT]) {
     // component-major: consecutive MFMAs go to DIFFERENT accumulators, so none waits for its predecessor's result
 #define TILE_MFMA_C(c)                                                                                     \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)           \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < NT; ++n)          \
         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[m].c, f.w[n].c, acc[m][n], 0, 0, 0);
     TILE_MFMA_C(x)
     TILE_MFMA_C(y)
@@ -267,33 +267,37 @@ __device__ __forceinline__ void tile_mfma(const TileFrag<MT>& f, f32x4 (&acc)[MT
 }
 
 // acc += A[rows, K] . W[cols, K]^T over nch 16-wide chunks (nch % 4 == 0: H is a multiple of 64), operands
-// k-chunk-major.  Four-stage register ring: the loads of chunk kc+3 are issued before the MFMAs of chunk kc, because
-// one chunk's MFMAs (8*MT x 32 cycles) are shorter than an L2 round trip -- with a single chunk in flight the BPTT tile
-// ran 2.8x off its MFMA time (133 us per launch at configs[2] against 48).
-template <int MT>
-__device__ __forceinline__ void tile_contract(f32x4 (&acc)[MT][2], const float* __restrict__ At, const int* arow,
+// k-chunk-major.  NS-stage register ring: the loads of chunk kc+NS-1 are issued before the MFMAs of chunk kc, because
+// one chunk's MFMAs (4*MT*NT x 32 cycles) are shorter than an L2 round trip -- with a single chunk in flight the BPTT
+// tile ran 2.8x off its MFMA time (133 us per launch at configs[2] against 48).  NS = 4 (2 for the 4x4 tile: its
+// chunk is 2048 MFMA cycles long and its fragments are 32 registers per stage).
+template <int MT, int NT, int NS>
+__device__ __forceinline__ void tile_contract(f32x4 (&acc)[MT][NT], const float* __restrict__ At, const int* arow,
                                               int RA, const float* __restrict__ Wt, const int* wrow, int RW,
                                               int nch, int q4) {
-    constexpr int NS = 4;
-    TileFrag<MT> f[NS];
+    TileFrag<MT, NT> f[NS];
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) tile_load<MT>(f[s], At, arow, RA, Wt, wrow, RW, s, q4);
+    for (int s = 0; s < NS - 1; ++s) tile_load<MT, NT>(f[s], At, arow, RA, Wt, wrow, RW, s, q4);
     for (int kc0 = 0; kc0 < nch; kc0 += NS) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int kn = kc0 + s + NS - 1;
-            if (kn < nch) tile_load<MT>(f[(s + NS - 1) % NS], At, arow, RA, Wt, wrow, RW, kn, q4);
-            tile_mfma<MT>(f[s], acc);
+            if (kn < nch) tile_load<MT, NT>(f[(s + NS - 1) % NS], At, arow, RA, Wt, wrow, RW, kn, q4);
+            tile_mfma<MT, NT>(f[s], acc);
         }
     }
 }
 
-// Forward: block = 16*MT rows x 128 gate columns (32 hidden units; wave w owns units [8w, 8w+8) of them).
-// grid (H/32, ceil(B / (16*MT)), jobs).  The pre-activations go through a per-wave LDS tile so that one lane gets
-// the four gates of one (row, unit); then the same fused cell update as lstm_fwd_step_kernel.
-template <int MT>
+// Forward: wave tile = 16*MT rows x 16*NT gate columns (4*NT hidden units); block = 4 waves side by side =
+// 16*MT rows x 64*NT columns.  grid (H / (16*NT), ceil(B / (16*MT)), jobs).  The pre-activations go through a
+// per-wave LDS tile so that one lane gets the four gates of one (row, unit); then the same fused cell update as
+// lstm_fwd_step_kernel.  (MT, NT) = (4, 4): 16 FLOP per byte, one block per CU at configs[2].
+template <int MT, int NT>
 __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LDT = 16 * NT + 1;     // LDS tile row stride
+    constexpr int UW = 4 * NT;           // hidden units per wave
+    constexpr int NS = (MT * NT >= 16) ? 2 : 4;  // 4x4: a 4-stage ring (364 registers) measured no faster than 2
     arcvae_set_prio(a.prio);
     const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     if (tr) a.trace[0] = wall_clock64();
@@ -302,76 +306,81 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
     const int B = a.B, H = a.H, G = 4 * a.H;
     const int r = lane & 15, q4 = (lane >> 4) * 4;
     const int row0 = blockIdx.y * 16 * MT;
-    const int wcol0 = blockIdx.x * 128 + wave * 32;  // permuted weight rows: 16 consecutive = 4 units x (i,f,g,o)
-    const int ubase = blockIdx.x * 32 + wave * 8;    // first hidden unit of this wave
-    int arow[MT], wrow[2];
+    const int wcol0 = (blockIdx.x * 4 + wave) * 16 * NT;  // permuted weight rows: 16 consecutive = 4 units x (i,f,g,o)
+    const int ubase = (blockIdx.x * 4 + wave) * UW;       // first hidden unit of this wave
+    int arow[MT], wrow[NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) arow[m] = min(row0 + 16 * m + r, B - 1);
-    wrow[0] = wcol0 + r;
-    wrow[1] = wcol0 + 16 + r;
-    f32x4 acc[MT][2];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wrow[n] = wcol0 + 16 * n + r;
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nch = H >> 4;
-    if (j.xin) tile_contract<MT>(acc, j.xin, arow, B, j.Wx, wrow, G, nch, q4);
-    if (j.hprev) tile_contract<MT>(acc, j.hprev, arow, B, j.Wh, wrow, G, nch, q4);
-    // accumulators -> per-wave LDS tile [16*MT][33]: D[row = 4*(lane>>4) + reg][col = lane & 15]
-    float* t = lds + wave * (16 * MT * 33);
+    if (j.xin) tile_contract<MT, NT, NS>(acc, j.xin, arow, B, j.Wx, wrow, G, nch, q4);
+    if (j.hprev) tile_contract<MT, NT, NS>(acc, j.hprev, arow, B, j.Wh, wrow, G, nch, q4);
+    // accumulators -> per-wave LDS tile [16*MT][LDT]: D[row = 4*(lane>>4) + reg][col = lane & 15]
+    float* t = lds + wave * (16 * MT * LDT);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) t[(16 * m + (lane >> 4) * 4 + reg) * 33 + 16 * n + r] = acc[m][n][reg];
+            for (int reg = 0; reg < 4; ++reg) t[(16 * m + (lane >> 4) * 4 + reg) * LDT + 16 * n + r] = acc[m][n][reg];
     __syncthreads();
-    // (row, unit) pairs of the wave: 16*MT rows x 8 units, 2*MT per lane.  All loads of all pairs are issued before
-    // the first store: the output pointers may alias the inputs as far as the compiler knows, so a load placed after a
-    // store would wait for it, and the token -> table-row -> cell chain would be paid 2*MT times in sequence.
-    constexpr int NP = 2 * MT;
-    int prow[NP], punit[NP];
-    long poff[NP];
+    // (row, unit) pairs of the wave: 16*MT rows x UW units = MT*NT per lane, handled in batches of <= 8.  Within a
+    // batch all loads of all pairs are issued before the first store: the output pointers may alias the inputs as far
+    // as the compiler knows, so a load placed after a store would wait for it, and the token -> table-row -> cell
+    // chain would be paid once per pair in sequence.
+    constexpr int NPAIR = MT * NT;
+    constexpr int NP = NPAIR < 8 ? NPAIR : 8;
 #pragma unroll
-    for (int it = 0; it < NP; ++it) {
-        const int idx = it * 64 + lane;
-        prow[it] = row0 + (idx >> 3);
-        punit[it] = ubase + (idx & 7);
-        const int rc = min(prow[it], B - 1);
-        long o = 0;
-        if (j.tok) {
-            int tk = j.tok[rc];
-            tk = min(max(tk, 0), a.V - 1);
-            o = (long)tk * G;
+    for (int b0 = 0; b0 < NPAIR; b0 += NP) {
+        int prow[NP], punit[NP];
+        long poff[NP];
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int idx = (b0 + it) * 64 + lane;
+            prow[it] = row0 + idx / UW;
+            punit[it] = ubase + idx % UW;
+            const int rc = min(prow[it], B - 1);
+            long o = 0;
+            if (j.tok) {
+                int tk = j.tok[rc];
+                tk = min(max(tk, 0), a.V - 1);
+                o = (long)tk * G;
+            }
+            poff[it] = o;
         }
-        poff[it] = o;
-    }
-    float pv[NP][4], cpv[NP];
+        float pv[NP][4], cpv[NP];
 #pragma unroll
-    for (int it = 0; it < NP; ++it) {
-        const float* pre = j.pre + poff[it] + punit[it];
-        pv[it][0] = pre[0]; pv[it][1] = pre[H]; pv[it][2] = pre[2 * H]; pv[it][3] = pre[3 * H];
-        cpv[it] = j.cprev ? j.cprev[(long)min(prow[it], B - 1) * H + punit[it]] : 0.f;
-    }
+        for (int it = 0; it < NP; ++it) {
+            const float* pre = j.pre + poff[it] + punit[it];
+            pv[it][0] = pre[0]; pv[it][1] = pre[H]; pv[it][2] = pre[2 * H]; pv[it][3] = pre[3 * H];
+            cpv[it] = j.cprev ? j.cprev[(long)min(prow[it], B - 1) * H + punit[it]] : 0.f;
+        }
 #pragma unroll
-    for (int it = 0; it < NP; ++it) {
-        const int idx = it * 64 + lane;
-        const int rl = idx >> 3, ul = idx & 7;
-        const int row = prow[it], unit = punit[it];
-        if (row >= B) continue;
-        const float* tp = t + rl * 33 + 16 * (ul >> 2) + (ul & 3);
-        const float gi = sigmoidf_acc(tp[0] + pv[it][0]);
-        const float gf = sigmoidf_acc(tp[4] + pv[it][1]);
-        const float gg = tanhf(tp[8] + pv[it][2]);
-        const float go = sigmoidf_acc(tp[12] + pv[it][3]);
-        const long hb = (long)row * H + unit;
-        const float c = j.cprev ? gf * cpv[it] + gi * gg : gi * gg;
-        const float hv = go * tanhf(c);
-        float* gp = j.gates + (long)row * G + unit;
-        gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
-        j.h[hb] = hv;
-        j.ht[((long)(unit >> 4) * B + row) * 16 + (unit & 15)] = hv;
-        j.c[hb] = c;
+        for (int it = 0; it < NP; ++it) {
+            const int idx = (b0 + it) * 64 + lane;
+            const int rl = idx / UW, ul = idx % UW;
+            const int row = prow[it], unit = punit[it];
+            if (row >= B) continue;
+            const float* tp = t + rl * LDT + 16 * (ul >> 2) + (ul & 3);
+            const float gi = sigmoidf_acc(tp[0] + pv[it][0]);
+            const float gf = sigmoidf_acc(tp[4] + pv[it][1]);
+            const float gg = tanhf(tp[8] + pv[it][2]);
+            const float go = sigmoidf_acc(tp[12] + pv[it][3]);
+            const long hb = (long)row * H + unit;
+            const float c = j.cprev ? gf * cpv[it] + gi * gg : gi * gg;
+            const float hv = go * tanhf(c);
+            float* gp = j.gates + (long)row * G + unit;
+            gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+            j.h[hb] = hv;
+            j.ht[((long)(unit >> 4) * B + row) * 16 + (unit & 15)] = hv;
+            j.c[hb] = c;
+        }
     }
     if (tr) a.trace[1] = wall_clock64();
 }
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (j.src) tile_contract<MT>(acc, j.src, arow, B, j.WT, wrow, H, G >> 4, q4);
+    if (j.src) tile_contract<MT, 2, 4>(acc, j.src, arow, B, j.WT, wrow, H, G >> 4, q4);
     const bool cell = j.kind == 0;
     // Epilogue per 16-row group m: the 8 (row, unit) elements of a lane are loaded together (clamped indices, no
     // branch between the loads) and only then computed and stored -- see the forward tile kernel.
@@ -460,15 +469,17 @@ inline int choose_tile_mt(int B, int col_blocks, int jobs) {
     const int force = arcvae_env_int("ARCVAE_STEP_TILE", -1);  // read per sweep call (tests toggle it)
     if (force == 0 || force == 22) return 0;
     if (force == 1 || force == 2 || force == 4) return force;
+    if (force == 44) return 4;
     const int mts[2] = {4, 2};  // MT = 1 never pays: at that size the all-loads-first 16x16 kernels are ahead
     for (int i = 0; i < 2; ++i)
         if (ceil_div(B, 16 * mts[i]) * col_blocks * jobs >= 200) return mts[i];
     return 0;
 }
 
-template <int MT>
-void launch_fwd_tile(const FwdArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_fwd_tile_kernel<MT>, grid, dim3(256), 4 * 16 * MT * 33 * sizeof(float), s, a);
+template <int MT, int NT>
+void launch_fwd_tile(const FwdArgs& a, int B, int H, int nj, hipStream_t s) {
+    dim3 grid(H / (16 * NT), ceil_div(B, 16 * MT), nj);
+    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT>), grid, dim3(256), 4 * 16 * MT * (16 * NT + 1) * sizeof(float), s, a);
 }
 template <int MT>
 void launch_bwd_tile(const BwdArgs& a, dim3 grid, hipStream_t s) {
@@ -673,7 +684,10 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             if (rc != ARCVAE_OK) return rc;
         }
     }
-    const int tile_mt = choose_tile_mt(B, H / 32, L);
+    int tile_mt = choose_tile_mt(B, H / 32, L);
+    const int tile_env = arcvae_env_int("ARCVAE_STEP_TILE", -1);
+    if (tile_env == 44 || (tile_mt == 4 && tile_env != 4 && ceil_div(B, 64) * (H / 64) * L >= 200))
+        tile_mt = 44;  // the 64 x 64 wave tile (16 FLOP per byte) when even its grid fills the chip; 44 forces it
     const int RS = arcvae_ring_slots(T);
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
@@ -697,10 +711,10 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
         }
         for (int k = nj; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
         if (tile_mt) {
-            dim3 tgrid(H / 32, ceil_div(B, 16 * tile_mt), nj);
-            if (tile_mt == 4) launch_fwd_tile<4>(a, tgrid, stream);
-            else if (tile_mt == 2) launch_fwd_tile<2>(a, tgrid, stream);
-            else launch_fwd_tile<1>(a, tgrid, stream);
+            if (tile_mt == 44) launch_fwd_tile<4, 4>(a, B, H, nj, stream);
+            else if (tile_mt == 4) launch_fwd_tile<4, 2>(a, B, H, nj, stream);
+            else if (tile_mt == 2) launch_fwd_tile<2, 2>(a, B, H, nj, stream);
+            else launch_fwd_tile<1, 2>(a, B, H, nj, stream);
             continue;
         }
         dim3 grid(H / 4, ceil_div(B, 16), nj);

@@ -205,7 +205,7 @@ def test_step_odd_vocabulary_and_embedding_sizes(V, E, Z, C, B, T):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("mt", [1, 2, 4, 22])  # 22 = the mid-batch 2x2 latency kernels
+@pytest.mark.parametrize("mt", [1, 2, 4, 44, 22])  # 44 = 64x64 forward wave tile, 22 = mid-batch 2x2 latency kernels
 @pytest.mark.parametrize("H,L,B,T,C", [(64, 2, 37, 6, 1), (192, 3, 70, 5, 2), (128, 1, 16, 4, 1), (256, 2, 130, 4, 1)])
 def test_tiled_large_batch_step_kernels(mt, H, L, B, T, C, monkeypatch):
     """The register-tiled step kernels (lstm_fwd_tile_kernel / lstm_bwd_tile_kernel: the large-batch path,
