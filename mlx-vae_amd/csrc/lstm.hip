@@ -588,6 +588,110 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step2_kernel(BwdArgs a) {
     }
     if (tr) a.trace[1] = wall_clock64();
 }
+
+// Mid-batch forward step kernel ("2x2"): see lstm_bwd_step2_kernel.  Block = 32 rows x 32 gate columns (8 hidden
+// units, permuted weight rows: 16 consecutive = 4 units x i,f,g,o), K split over the 4 waves, 2 x 2 fragments per wave
+// and source, every load before the first MFMA; the 256 threads each own one (row, unit) of the cell update.
+template <int CH>
+__global__ __launch_bounds__(256) void lstm_fwd_step2_kernel(FwdArgs a) {
+    __shared__ float red[4 * 1024];  // [wave][32 rows][32 cols]
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
+    const FwdJob& j = a.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H, G = 4 * a.H;
+    const int bx = xcd_group_block(blockIdx.x, gridDim.x, a.remap);  // 4 consecutive blocks fill a 128-B line of h / c
+    const int r0 = blockIdx.y * 32, u0 = bx * 8;
+    // epilogue role first: thread -> (row = tid >> 3, unit = u0 + (tid & 7)); token -> table row is a dependent pair
+    const int erow = tid >> 3, ul = tid & 7;
+    const int eb = min(r0 + erow, B - 1);
+    const int unit = u0 + ul;
+    const float* pre = j.pre;
+    if (j.tok) {
+        int tk = j.tok[eb];
+        tk = min(max(tk, 0), a.V - 1);
+        pre += (long)tk * G;
+    }
+    const float p0 = pre[unit], p1 = pre[H + unit], p2 = pre[2 * H + unit], p3 = pre[3 * H + unit];
+    const long hb = (long)eb * H + unit;
+    const float cprev_v = j.cprev ? j.cprev[hb] : 0.f;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    const int arow0 = min(r0 + r, B - 1), arow1 = min(r0 + 16 + r, B - 1);
+    const int wrow0 = bx * 32 + r, wrow1 = bx * 32 + 16 + r;
+    const bool s1 = j.xin != nullptr, s2 = j.hprev != nullptr;
+    float4 fa1[2][CH], fw1[2][CH], fa2[2][CH], fw2[2][CH];
+    if (s1) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {   // wave w owns chunks [w*CH, (w+1)*CH) of the H/16 chunks of a source
+            const long kc = wave * CH + c;
+            fa1[0][c] = *reinterpret_cast<const float4*>(j.xin + (kc * B + arow0) * 16 + q4);
+            fa1[1][c] = *reinterpret_cast<const float4*>(j.xin + (kc * B + arow1) * 16 + q4);
+            fw1[0][c] = *reinterpret_cast<const float4*>(j.Wx + (kc * G + wrow0) * 16 + q4);
+            fw1[1][c] = *reinterpret_cast<const float4*>(j.Wx + (kc * G + wrow1) * 16 + q4);
+        }
+    }
+    if (s2) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const long kc = wave * CH + c;
+            fa2[0][c] = *reinterpret_cast<const float4*>(j.hprev + (kc * B + arow0) * 16 + q4);
+            fa2[1][c] = *reinterpret_cast<const float4*>(j.hprev + (kc * B + arow1) * 16 + q4);
+            fw2[0][c] = *reinterpret_cast<const float4*>(j.Wh + (kc * G + wrow0) * 16 + q4);
+            fw2[1][c] = *reinterpret_cast<const float4*>(j.Wh + (kc * G + wrow1) * 16 + q4);
+        }
+    }
+#define STEP2F_MFMA(FA, FW, comp)                                                                             \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)               \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m][c].comp, FW[n][c].comp, acc[m][n], 0, 0, 0);
+    if (s1) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { STEP2F_MFMA(fa1, fw1, x) STEP2F_MFMA(fa1, fw1, y) STEP2F_MFMA(fa1, fw1, z) STEP2F_MFMA(fa1, fw1, w) }
+    }
+    if (s2) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { STEP2F_MFMA(fa2, fw2, x) STEP2F_MFMA(fa2, fw2, y) STEP2F_MFMA(fa2, fw2, z) STEP2F_MFMA(fa2, fw2, w) }
+    }
+#undef STEP2F_MFMA
+    {
+        float* p = red + wave * 1024;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    p[(16 * m + (lane >> 4) * 4 + reg) * 32 + 16 * n + (lane & 15)] = acc[m][n][reg];
+    }
+    __syncthreads();
+    if (r0 + erow < B) {
+        // tile column of (unit ul, gate g): 16 * (ul >> 2) + 4 * g + (ul & 3)
+        const int cb = erow * 32 + 16 * (ul >> 2) + (ul & 3);
+        float v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            v[g] = (red[cb + 4 * g] + red[1024 + cb + 4 * g]) + (red[2048 + cb + 4 * g] + red[3072 + cb + 4 * g]);
+        const float gi = sigmoidf_acc(v[0] + p0), gf = sigmoidf_acc(v[1] + p1), gg = tanhf(v[2] + p2),
+                    go = sigmoidf_acc(v[3] + p3);
+        const float c = j.cprev ? gf * cprev_v + gi * gg : gi * gg;
+        const float hv = go * tanhf(c);
+        float* gp = j.gates + (long)eb * G + unit;
+        gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+        j.h[hb] = hv;
+        j.ht[((long)(unit >> 4) * B + eb) * 16 + (unit & 15)] = hv;
+        j.c[hb] = c;
+    }
+    if (tr) a.trace[1] = wall_clock64();
+}
+template <int CH>
+void launch_fwd2(const FwdArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_fwd_step2_kernel<CH>, grid, dim3(256), 0, s, a);
+}
 template <int CH>
 void launch_bwd2(const BwdArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(lstm_bwd_step2_kernel<CH>, grid, dim3(1024), 0, s, a);
@@ -688,6 +792,7 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     const int tile_env = arcvae_env_int("ARCVAE_STEP_TILE", -1);
     if (tile_env == 44 || (tile_mt == 4 && tile_env != 4 && ceil_div(B, 64) * (H / 64) * L >= 200))
         tile_mt = 44;  // the 64 x 64 wave tile (16 FLOP per byte) when even its grid fills the chip; 44 forces it
+    const bool step2 = !tile_mt && choose_step2(B);
     const int RS = arcvae_ring_slots(T);
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
@@ -715,6 +820,11 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             else if (tile_mt == 4) launch_fwd_tile<4, 2>(a, B, H, nj, stream);
             else if (tile_mt == 2) launch_fwd_tile<2, 2>(a, B, H, nj, stream);
             else launch_fwd_tile<1, 2>(a, B, H, nj, stream);
+            continue;
+        }
+        if (step2) {
+            dim3 grid2(H / 8, ceil_div(B, 32), nj);
+            DISPATCH_CH(H, launch_fwd2, a, grid2, stream)
             continue;
         }
         dim3 grid(H / 4, ceil_div(B, 16), nj);
