@@ -233,3 +233,65 @@ def test_tiled_large_batch_step_kernels(mt, H, L, B, T, C, monkeypatch):
         elif rel_err(got, g) >= TOL:
             bad[name] = rel_err(got, g)
     assert not bad, bad
+
+
+def test_config3_full_size_kernel_families_agree(monkeypatch):
+    """BASELINE.json configs[2] at FULL size (H512 Z256 L4, bs 512, T 128), where the CPU oracle would take minutes:
+    size-independent properties instead.  (1) The register-tiled large-batch step kernels and the latency kernels --
+    each checked against the oracle at small shapes -- give the same losses and gradients; (2) dead decoder
+    parameters (Q1/Q2) receive exactly zero gradient; (3) the loss does not depend on eps (Q2)."""
+    cfg = O.Config(vocab_size=80, embedding_dim=128, hidden_dim=512, latent_dim=256, num_conditions=1, num_layers=4)
+    B, T = 512, 128
+    params = O.init_params(cfg, 1234)
+    x, cond = O.synthetic_batch(cfg, B, T, 67)
+    eps = np.random.RandomState(4321).standard_normal((B, cfg.Z)).astype(np.float32)
+    coins = O.draw_coins(np.random.RandomState(68), T, 0.9)
+    res = {}
+    for mode in ("-1", "0"):  # auto (tiled kernels at this size) vs the 16x16 latency kernels
+        monkeypatch.setenv("ARCVAE_STEP_TILE", mode)
+        eng, enc, dec = build_engine(cfg, params)
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+        torch.cuda.synchronize()
+        eng.check_gates()
+        res[mode] = (np.array([float(out[k]) for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info")]),
+                     enc.grad.cpu().numpy().copy(), dec.grad.cpu().numpy().copy(), out["mu"].cpu().numpy().copy())
+        if mode == "-1":
+            for name in ("z_to_hidden.weight", "condition_to_hidden.weight", "lstm_layer_0.Wh", "lstm_layer_3.Wh"):
+                assert float(dec.g(name).abs().max()) == 0.0, name
+            out2 = eng.train_step(x, cond, eps * 2.0 - 0.5, coins, lr=2e-4, update=False, **HYPER)
+            torch.cuda.synchronize()
+            assert float(out2["recon_loss"]) == float(out["recon_loss"])
+        del eng, enc, dec
+        torch.cuda.empty_cache()
+    a, b = res["-1"], res["0"]
+    assert np.all(np.isfinite(a[0])) and np.allclose(a[0], b[0], rtol=2e-5, atol=1e-6), (a[0], b[0])
+    assert rel_err(a[3], b[3]) < 1e-5
+    assert rel_err(a[1], b[1]) < 1e-4 and rel_err(a[2], b[2]) < 1e-4
+
+
+@pytest.mark.parametrize("B", [256, 2048])
+def test_default_model_large_batches_kernel_families_agree(B, monkeypatch):
+    """BASELINE.json configs[3] shapes of the default model at full T = 128: 256 rows (one GPU's shard of the global
+    batch 2048: mid-batch 2x2 kernels) and 2048 rows (the whole global batch on one GPU: register-tiled kernels)
+    against the 16x16 latency kernels."""
+    cfg = DEFAULT
+    T = 128
+    params = O.init_params(cfg, 1234)
+    x, cond = O.synthetic_batch(cfg, B, T, 67)
+    eps = np.random.RandomState(4321).standard_normal((B, cfg.Z)).astype(np.float32)
+    coins = O.draw_coins(np.random.RandomState(68), T, 0.9)
+    res = {}
+    for mode in ("-1", "0"):
+        monkeypatch.setenv("ARCVAE_STEP_TILE", mode)
+        eng, enc, dec = build_engine(cfg, params)
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+        torch.cuda.synchronize()
+        eng.check_gates()
+        res[mode] = (np.array([float(out[k]) for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info")]),
+                     enc.grad.cpu().numpy().copy(), out["mu"].cpu().numpy().copy())
+        del eng, enc, dec
+        torch.cuda.empty_cache()
+    a, b = res["-1"], res["0"]
+    assert np.all(np.isfinite(a[0])) and np.allclose(a[0], b[0], rtol=2e-5, atol=1e-6), (a[0], b[0])
+    assert rel_err(a[2], b[2]) < 1e-5
+    assert rel_err(a[1], b[1]) < 1e-4
