@@ -58,7 +58,7 @@ def _worker(rank, world, port, cfg_name, B, T, ret):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("cfg_name,B,T", [("tiny", 8, 12), ("small", 21, 9)])
+@pytest.mark.parametrize("cfg_name,B,T", [("tiny", 8, 12), ("small", 21, 9), ("tiny", 6, 2)])  # T = 2: single-chunk sweep
 def test_two_ranks_one_gpu_equal_single_process(cfg_name, B, T):
     world = 2
     mgr = mp.Manager()
