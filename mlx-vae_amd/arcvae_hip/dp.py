@@ -8,10 +8,10 @@ step needs exactly two exchanges:
   1. forward seam : all-reduce(SUM) of `stats` (2Z+4 floats: sum mu, sum exp(logvar), KL sums,
                     row count, CE row-sum) -> every rank evaluates the GLOBAL loss scalars and
                     the MI gate, and differentiates them w.r.t. its LOCAL rows (1/B_global scaling);
-  2. backward     : all-reduce(SUM) of the flat gradient buffers -- ONE 9.2 MB bucket [enc.grad |
-                    dec.grad | CE sum] on the main stream behind the BPTT sweep (gated form, see
-                    EngineOps), or one bucket per module with the decoder's reduced on a comm stream
-                    beside the sweep (event form).  Messages are <= 9.2 MB: on point-to-point xGMI RCCL
+  2. backward     : all-reduce(SUM) of the flat gradient buffers -- one contiguous bucket [enc.grad |
+                    dec.grad | CE sum] reduced in two pieces on the main stream behind the BPTT sweep (gated
+                    form, see EngineOps), or one bucket per module with the decoder's reduced on a comm stream
+                    beside the sweep (event form).  Messages are <= 5.3 MB: on point-to-point xGMI RCCL
                     picks a direct reduce-scatter/all-gather rather than a per-link-bound ring (SURVEY
                     section 5).
 
@@ -85,14 +85,16 @@ class EngineOps:
 
     Gated form (default; engine.Gates -- side/aux wait in device-side gate kernels, no blocked hardware queue):
       main stream : signal -> [enc_fwd] -> (all-reduce stats) -> [loss + dcomb + sweep chunks + signals]
-                    -> join aux, side -> [CE sum] -> (all-reduce ONE bucket: enc.grad | dec.grad | CE sum)
-                    -> [finalize + adam]
+                    -> gate on side's decoder -> [CE sum] -> (all-reduce dec.grad | CE sum: overlaps the last
+                    weight-gradient chunk on aux / side) -> join aux, side -> (all-reduce enc.grad) -> [finalize + adam]
       side stream : gate -> [dec_fwd + dec_bwd] ... gate -> [tail chunk's token-table half]
       aux stream  : gate -> [weight gradients of chunk c] ...
-      Two collectives per step, both on the main stream.  The gradient bucket is one contiguous buffer (the stores'
-      `grad` tensors are re-pointed into it), so the whole backward exchange is a single 9.2 MB all-reduce behind
-      the sweep; the decoder's 3.9 MB share is not overlapped with the BPTT sweep any more (~2 % at 8 GPUs), which
-      buys a step without any cross-stream event wait while the chain runs.
+      Three collectives per step, all on the main stream and one communicator (issue order = execution order on
+      every rank).  The gradient bucket is one contiguous buffer (the stores' `grad` tensors are re-pointed into it)
+      reduced in two pieces: the decoder's 3.9 MB right behind the sweep, beside the tail of the weight-gradient
+      work, the encoder's 5.3 MB after the join.  The decoder's share is not overlapped with the BPTT sweep itself
+      any more (that needed a second stream blocked on events), which buys a step without any cross-stream event
+      wait while the chain runs.
 
     Event form (fallback when the gate probe fails, ARCVAE_GATES=0): as in round 1 --
       side: [dec_fwd] -> ev_chain -> [dec_bwd] -> ev_dec_bwd;  comm stream: CE sum and dec.grad reduced beside the
@@ -141,6 +143,8 @@ class EngineOps:
             eng._graphs.clear()
             self.run = eng.runner(self.ws, self.lr, self.global_rows, capture=self.run.capture)
         self.bucket = cur
+        self.bucket_enc = cur[:ne]               # complete after the join (last weight-gradient chunk)
+        self.bucket_dec = cur[ne:ne + nd + 64]   # decoder gradients + CE sum: complete long before the sweep ends
         self.bucket_recon = cur[ne + nd:ne + nd + 1]
 
     # ---- gated form ---------------------------------------------------------------------------------
@@ -157,15 +161,20 @@ class EngineOps:
         eng.enqueue_encoder_forward(ws, self.run)
 
     def _recon_gated(self) -> None:
-        # main has joined side and aux (enqueue_backward): CE row sums -> the bucket's last cell
-        eng, ws = self.eng, self.ws
+        # behind the BPTT sweep on main: once side reports its decoder segment done (gate on D: finished ~1 ms ago),
+        # CE row sums -> the bucket's last cell; the [dec.grad | CE sum] half of the bucket is then reduced while
+        # aux and side are still busy with the last chunk's weight gradients
+        eng, ws, g = self.eng, self.ws, self.eng.gates
         Z = eng.d.Z
         base = C.c_void_p(self.bucket_recon.data_ptr() - 4 * (2 * Z + 3))
 
         def fn():
-            eng.gates.join()   # aux and side have reported their last piece of the step
+            g.wait(g.D, g.NM, 1, 1)    # ticket of main's current step; NM is advanced by the join below
             call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, base, Z, stream_ptr())
         self.run("dp_recon", fn, torch.cuda.current_stream())
+
+    def _join_gated(self) -> None:
+        self.run("dp_join", self.eng.gates.join, torch.cuda.current_stream())  # aux and side reported their last piece
 
     def _finish_gated(self) -> None:
         from .engine import adam_update
@@ -214,13 +223,14 @@ class EngineOps:
 
     def early_buckets(self) -> List[torch.Tensor]:
         if self.gated:
-            return []
+            return [self.bucket_dec]
         torch.cuda.current_stream().wait_event(self.eng.ev_dec_bwd)
         return [self.eng.dec.grad]
 
     def late_buckets(self) -> List[torch.Tensor]:
         if self.gated:
-            return [self.bucket]
+            self._join_gated()
+            return [self.bucket_enc]
         return [self.eng.enc.grad]
 
     def apply_update(self) -> None:

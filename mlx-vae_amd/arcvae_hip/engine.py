@@ -207,16 +207,17 @@ class Gates:
     almost all the time).  With gates the waiting stream runs a one-wave polling kernel instead.
 
     Words (one 128-B line each):  P main's signal count (exactly STRIDE per step), Q aux's (1 per step),
-    R completions of aux + side (2 per step: main's join before the optimizer step), NS / NA / NM steps finished by
+    R completions of aux + side (2 per step: main's join before the optimizer step), D decoder segments finished by side
+    (1 per step: the data-parallel step reduces the decoder's gradients early), NS / NA / NM steps finished by
     side / aux / main (the waiter's own ticket counter), ERR expired gates, PROBE self-test.
     """
     STRIDE = 8
     LONG, SHORT = 16_000_000, 3_000    # polls (~1.5 us each): ~25 s before a gate gives up (a first RCCL collective
                                        # or a peer still capturing its graphs may hold main up for seconds); ~4 ms probe
-    P, Q, NS, NA, ERR, PROBE, R, NM = range(8)
+    P, Q, NS, NA, ERR, PROBE, R, NM, D = range(9)
 
     def __init__(self, device):
-        self.mem = torch.zeros(8 * 32, dtype=torch.int32, device=device)
+        self.mem = torch.zeros(9 * 32, dtype=torch.int32, device=device)
         self._probed: Dict[Tuple[int, int], bool] = {}
 
     def word(self, i: int) -> C.c_void_p:
@@ -588,6 +589,10 @@ class StepEngine:
             decoder_backward(self.dec, ws, d, 1.0 / (global_rows * ws.T))
             if adam_lr is not None:
                 adam_update(self.dec, adam_lr)
+            if gate is not None:
+                # decoder gradients and CE row sums of this step are complete (read by the data-parallel step, which
+                # reduces them early; raised in every gated step so that D stays in lockstep with main's step count)
+                gate[0].signal(Gates.D, 1)
 
         if backward and not split_events:  # single process: one side-stream segment (one graph launch less)
             run("dec_all", lambda: (dec_fwd(), dec_bwd()), self.side)

@@ -68,8 +68,8 @@ def test_gated_step_equals_event_ordered_step(cfg, B, T, monkeypatch):
         if gates == "1":
             assert eng._gating_ok(torch.cuda.current_stream()), "no distinct hardware queues found on this box"
             g = eng.gates
-            P, Q, NS, NA, R, NM = (int(g.mem[32 * i]) for i in (g.P, g.Q, g.NS, g.NA, g.R, g.NM))
-            assert (P, Q, NS, NA, R, NM) == (4 * g.STRIDE, 4, 4, 4, 8, 4)
+            P, Q, NS, NA, R, NM, D = (int(g.mem[32 * i]) for i in (g.P, g.Q, g.NS, g.NA, g.R, g.NM, g.D))
+            assert (P, Q, NS, NA, R, NM, D) == (4 * g.STRIDE, 4, 4, 4, 8, 4, 4)
         res[gates] = (np.stack(losses), enc.flat.cpu().numpy(), dec.flat.cpu().numpy(), enc.grad.cpu().numpy())
     a, b = res["1"], res["0"]
     assert np.allclose(a[0], b[0], rtol=2e-5, atol=2e-6)
@@ -91,6 +91,6 @@ def test_gated_steps_across_workspaces_keep_tickets_in_step():
     eng.check_gates()
     if eng._gating_ok(torch.cuda.current_stream()):
         g = eng.gates
-        P, Q, NS, NA, R, NM = (int(g.mem[32 * i]) for i in (g.P, g.Q, g.NS, g.NA, g.R, g.NM))
-        assert (P, Q, NS, NA, R, NM) == (n * g.STRIDE, n, n, n, 2 * n, n)
+        P, Q, NS, NA, R, NM, D = (int(g.mem[32 * i]) for i in (g.P, g.Q, g.NS, g.NA, g.R, g.NM, g.D))
+        assert (P, Q, NS, NA, R, NM, D) == (n * g.STRIDE, n, n, n, 2 * n, n, n)
     assert np.isfinite(eng.workspace(3, 12).scalars.cpu().numpy()[:9]).all()
