@@ -113,3 +113,29 @@ def test_segsum_and_colsum():
     np.add.at(ref, seg, X.astype(np.float64))
     assert rel_err(out.cpu().numpy(), ref) < TOL
     assert rel_err(cs.cpu().numpy(), X.astype(np.float64).sum(0)) < TOL
+
+
+@pytest.mark.parametrize("V,E,C,G", [(80, 128, 0, 1024), (80, 128, 1, 1024), (95, 20, 2, 256), (33, 130, 3, 512), (127, 18, 0, 256)])
+def test_table_finalize(V, E, C, G):
+    """arcvae_table_finalize: dEmb += dT . Wx0[:, :E];  dWx0[:, :E] += dT^T . emb (row stride E + C);  db0 += colsum(dT)
+    -- the backward of nn.Embedding + the x . Wx^T term of the layer-0 nn.LSTM (models/encoder.py:93,98,
+    models/decoder.py:154-166) through the [V,4H] token table.  '+=' semantics, columns E..E+C-1 untouched."""
+    from arcvae_hip import _lib
+    rs = np.random.RandomState(V + E)
+    dT = rs.standard_normal((V, G)); Wx0 = rs.standard_normal((G, E + C)); emb = rs.standard_normal((V, E))
+    dEmb0 = rs.standard_normal((V, E)); dWx0_0 = rs.standard_normal((G, E + C)); db0_0 = rs.standard_normal(G)
+    d = {k: _dev(v) for k, v in dict(dT=dT, Wx0=Wx0, emb=emb, dEmb=dEmb0, dWx0=dWx0_0, db0=db0_0).items()}
+    _lib.call("arcvae_table_finalize", _lib.ptr(d["dT"]), _lib.ptr(d["Wx0"]), E + C, _lib.ptr(d["emb"]),
+              _lib.ptr(d["dEmb"]), _lib.ptr(d["dWx0"]), _lib.ptr(d["db0"]), V, E, G, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert rel_err(d["dEmb"].cpu().numpy(), dEmb0 + dT @ Wx0[:, :E]) < TOL
+    want = dWx0_0.copy()
+    want[:, :E] += dT.T @ emb
+    got = d["dWx0"].cpu().numpy()
+    assert rel_err(got, want) < TOL
+    if C:
+        assert np.array_equal(got[:, E:], dWx0_0[:, E:].astype(np.float32))
+    assert rel_err(d["db0"].cpu().numpy(), db0_0 + dT.sum(0)) < TOL
+    with pytest.raises(_lib.ArcvaeHipError):
+        _lib.call("arcvae_table_finalize", _lib.ptr(d["dT"]), _lib.ptr(d["Wx0"]), E - 1, _lib.ptr(d["emb"]),
+                  _lib.ptr(d["dEmb"]), _lib.ptr(d["dWx0"]), _lib.ptr(d["db0"]), V, E, G, _lib.stream_ptr())
