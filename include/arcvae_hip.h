@@ -108,6 +108,10 @@ int arcvae_latent_loss(const float* stats, const float* hyper, const float* mu, 
 /* recon = stats[2Z+3]/(B_global*T) and total, once the decoder's CE row sums are in stats (latent_loss may run
  * before that: the encoder's backward does not depend on the reconstruction term, Q2). */
 int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, arcvae_stream_t stream);
+/* arcvae_stats_set_recon + arcvae_loss_finalize in one launch (single-process step: losses/recon.py:59-60 mean over
+ * B*T and complete_vae_loss.py:76-82 total). */
+int arcvae_recon_finalize(const float* rowloss, int B, float* stats, float* scalars, int Z, int T,
+                          arcvae_stream_t stream);
 int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* Wlh, const float* Wlv,
                               const float* comb, const float* lh, const float* dmu_raw, const float* dlv_raw,
                               float* dlh, float* dcomb, float* dWc, float* dbc, float* dWmu, float* dbmu,

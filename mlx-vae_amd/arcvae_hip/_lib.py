@@ -39,6 +39,7 @@ SIGNATURES = {
     "arcvae_stats_set_recon": [_vp, _i, _vp, _i, _vp],
     "arcvae_latent_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "arcvae_loss_finalize": [_vp, _vp, _i, _i, _vp],
+    "arcvae_recon_finalize": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "arcvae_enc_heads_backward": [_vp] * 18 + [_i, _i, _i, _i, _i, _vp],
     "arcvae_dec_forward_dense": [_vp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _i, _i, _i, _f, _vp],

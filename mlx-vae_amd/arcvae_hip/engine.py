@@ -652,9 +652,11 @@ class StepEngine:
         def fin():
             if gates is not None:
                 gates.join()
-            if with_recon:
-                self._recon(ws)
-            call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
+            if with_recon:   # CE sum + recon/total scalars in one launch
+                call("arcvae_recon_finalize", ptr(ws.rowloss), ws.B, ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T,
+                     stream_ptr())
+            else:
+                call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
             if update:
                 if dec_adam:
                     adam_update(self.dec, lr)

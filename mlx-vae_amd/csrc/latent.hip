@@ -260,6 +260,36 @@ __global__ void loss_finalize_kernel(const float* __restrict__ stats, float* sca
 }
 }  // namespace
 
+namespace {
+// CE row sums -> stats[2Z+3], then the recon / total scalars: arcvae_stats_set_recon + arcvae_loss_finalize in one
+// launch (both sit in the exposed tail of the single-process step)
+__global__ __launch_bounds__(256) void recon_finalize_kernel(const float* __restrict__ rowloss, int n, float* stats,
+                                                             float* scalars, int Z, int T) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += rowloss[i];
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ce = (red[0] + red[1]) + (red[2] + red[3]);
+        stats[2 * Z + 3] = ce;
+        const float recon = ce / (stats[2 * Z + 2] * (float)T);
+        scalars[1] = recon;
+        scalars[0] = recon + scalars[3] + scalars[4] + scalars[6] + scalars[8];
+    }
+}
+}  // namespace
+
+// stats[2Z+3] = sum_b rowloss[b], then as arcvae_loss_finalize: one launch (single-process step; under data
+// parallelism the CE sum is all-reduced between the two, so the two separate entry points stay)
+extern "C" int arcvae_recon_finalize(const float* rowloss, int B, float* stats, float* scalars, int Z, int T,
+                                     hipStream_t stream) {
+    if (!rowloss || !stats || !scalars || B <= 0 || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(recon_finalize_kernel, dim3(1), dim3(256), 0, stream, rowloss, B, stats, scalars, Z, T);
+    return arcvae_launch_status();
+}
+
 extern "C" int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, hipStream_t stream) {
     if (!stats || !scalars || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, scalars, Z, T);

@@ -62,22 +62,40 @@ struct TileJobs {
     int mode[16];
 };
 __global__ __launch_bounds__(256) void tile_weights_kernel(TileJobs j, int H) {
+    // Both layouts move 16-byte pieces: mode 0 keeps 4 consecutive k together (a float4 of the source row is a float4
+    // of the destination), mode 1 is a [16 rows x 64 k] transpose through LDS (reads coalesced along k, writes 16
+    // consecutive rows of one k = 64 B, as float4 per thread).  K % 64 == 0 (H is a multiple of 64).
+    __shared__ float tile[16][65];
     const int z = blockIdx.y;
     const int K = j.cols[z];
-    const long n = (long)4 * H * K;
     const float* __restrict__ src = j.src[z];
     float* dst = j.dst[z];
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / K), k = (int)(i - (long)r * K);
-        long o;
-        if (j.mode[z] == 0) {
+    const int tid = threadIdx.x;
+    if (j.mode[z] == 0) {
+        const long n4 = (long)4 * H * K / 4;
+        const int k4n = K >> 2;
+        for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+            const int r = (int)(i / k4n), k = (int)(i - (long)r * k4n) * 4;
             const int gate = r / H, unit = r - gate * H;
             const int rp = (unit >> 2) * 16 + gate * 4 + (unit & 3);
-            o = ((long)(k >> 4) * 4 * H + rp) * 16 + (k & 15);
-        } else {
-            o = ((long)(r >> 4) * K + k) * 16 + (r & 15);
+            *reinterpret_cast<float4*>(dst + ((long)(k >> 4) * 4 * H + rp) * 16 + (k & 15)) =
+                *reinterpret_cast<const float4*>(src + (long)r * K + k);
         }
-        dst[o] = src[i];
+        return;
+    }
+    const int ktiles = K >> 6, ntiles = (4 * H / 16) * ktiles;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int R = t / ktiles, k0 = (t - R * ktiles) * 64;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                 // 1024 elements: row = (tid >> 6) + 4e, col = tid & 63
+            const int rr = (tid >> 6) + 4 * e, kk = tid & 63;
+            tile[rr][kk] = src[(long)(R * 16 + rr) * K + k0 + kk];
+        }
+        __syncthreads();
+        const int kk = tid >> 2, r4 = (tid & 3) * 4;
+        float4 v = make_float4(tile[r4][kk], tile[r4 + 1][kk], tile[r4 + 2][kk], tile[r4 + 3][kk]);
+        *reinterpret_cast<float4*>(dst + ((long)R * K + k0 + kk) * 16 + r4) = v;
     }
 }
 
@@ -325,7 +343,7 @@ extern "C" int arcvae_tile_weights(const float* const* src, float* const* dst, c
     TileJobs j;
     for (int i = 0; i < 16; ++i) {
         const int k = i < n ? i : 0;
-        if (!src[k] || !dst[k] || cols[k] <= 0 || (cols[k] % 16) != 0) return ARCVAE_ERR_ARG;
+        if (!src[k] || !dst[k] || cols[k] <= 0 || (cols[k] % 64) != 0) return ARCVAE_ERR_ARG;
         j.src[i] = src[k]; j.dst[i] = dst[k]; j.cols[i] = cols[k]; j.mode[i] = mode[k];
     }
     hipLaunchKernelGGL(tile_weights_kernel, dim3(256, n), dim3(256), 0, stream, j, H);
