@@ -155,10 +155,10 @@ class EngineOps:
         from .engine import EncoderBackwardPlan
         eng, ws, g = self.eng, self.ws, self.eng.gates
         nc = len(EncoderBackwardPlan(eng.enc, ws, eng.d).chunks)
-        g.signal(g.P, 1)
+        # signal #1 is raised by the forward sweep when it starts; the decoder is enqueued behind it (engine.py)
+        eng.enqueue_encoder_forward(ws, self._grun, start_signal=g.word(g.P))
         eng.enqueue_decoder(ws, self.global_rows, self._grun, wait_current=False, split_events=False,
                             gate=(g, nc < 2))
-        eng.enqueue_encoder_forward(ws, self.run)
 
     def _recon_gated(self) -> None:
         # behind the BPTT sweep on main: once side reports its decoder segment done (gate on D: finished ~1 ms ago),

@@ -91,6 +91,7 @@ class Workspace:
         self.logvar = torch.empty(B, Z, **f32)
         self.z = torch.empty(B, Z, **f32)
         self.stats = torch.zeros(2 * Z + 4, **f32)
+        self.psync = torch.zeros(272, **i32)     # scratch of the persistent forward sweep (flags, roles, error word)
         self.scalars = torch.zeros(16, **f32)
         # decoder forward (dense over B*V rows)
         self.tableD = torch.empty(V, G, **f32)
@@ -132,8 +133,15 @@ def _layer_ptrs(store: ParamStore, L: int, leaf: str, grad: bool = False, skip0:
 # --------------------------------------------------------------------------------------------
 # op-level drivers (each is a handful of C-ABI calls on the current stream)
 # --------------------------------------------------------------------------------------------
-def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: float) -> None:
-    """models/encoder.py:76-153 + per-rank latent statistics."""
+def persistent_forward_ok(ws: Workspace, d: ModelDims) -> bool:
+    """The forward sweep of this shape can run as one persistent launch (csrc/lstm.hip: lstm_fwd_persist_kernel)."""
+    return _lib.load().arcvae_enc_lstm_persistent_ok(ws.B, ws.T, d.H, d.L) == 1
+
+
+def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: float,
+                    start_signal: Optional[C.c_void_p] = None) -> None:
+    """models/encoder.py:76-153 + per-rank latent statistics.  start_signal (persistent sweep only): device word
+    bumped when the sweep starts."""
     B, T = ws.B, ws.T
     G = 4 * d.H
     s = stream_ptr()
@@ -144,9 +152,16 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
     wx, _k1 = _layer_ptrs(enc, d.L, "Wx", skip0=True)
     wh, _k2 = _layer_ptrs(enc, d.L, "Wh")
     bs, _k3 = _layer_ptrs(enc, d.L, "bias", skip0=True)
-    call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
-         ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), ptr(ws.wT) if hasattr(ws, "wT") else C.c_void_p(0), B, T, d.V,
-         d.H, d.L, s)
+    wT = ptr(ws.wT) if hasattr(ws, "wT") else C.c_void_p(0)
+    if persistent_forward_ok(ws, d):
+        call("arcvae_enc_lstm_forward_persistent", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq),
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, ptr(ws.psync),
+             start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L, s)
+    else:
+        if start_signal is not None:
+            call("arcvae_gate_set", start_signal, 1, 1, s)
+        call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, s)
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
          ptr(enc.p("condition_fc.bias")), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
@@ -529,6 +544,10 @@ class StepEngine:
         """Raise if a gate ever gave up waiting (results after that point are not ordered).  Host sync."""
         if self.gates is not None and self.gates.errors() != 0:
             raise _lib.ArcvaeHipError("a device-side gate expired (stream ordering was lost); set ARCVAE_GATES=0")
+        for ws in self._ws.values():
+            if int(ws.psync[264].item()) != 0:
+                raise _lib.ArcvaeHipError("the persistent forward sweep gave up waiting (no 32 resident blocks per XCD "
+                                          "or a stalled block); set ARCVAE_PERSIST=0")
 
     # ---- buffers ----------------------------------------------------------------------------
     def workspace(self, B: int, T: int, train: bool = True) -> Workspace:
@@ -536,8 +555,27 @@ class StepEngine:
         if key not in self._ws:
             if (B, T, True) in self._ws:  # a training workspace also serves forward-only calls
                 return self._ws[(B, T, True)]
-            self._ws[key] = Workspace(self.d, B, T, self.device, train)
+            ws = Workspace(self.d, B, T, self.device, train)
+            self._ws[key] = ws
+            self._probe_persistent(ws)
         return self._ws[key]
+
+    def _probe_persistent(self, ws: Workspace) -> None:
+        """The persistent forward sweep assumes 8 XCDs x 32 CUs with one resident block per CU.  Dry-run it once per
+        process on the first eligible workspace; if any block gives up (a partitioned or CU-masked device, a different
+        part), switch the whole process to the per-step launches."""
+        if getattr(StepEngine, "_persist_probed", False) or not persistent_forward_ok(ws, self.d):
+            return
+        StepEngine._persist_probed = True
+        torch.cuda.synchronize()
+        ws.x_tb.zero_()
+        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]))
+        torch.cuda.synchronize()
+        if int(ws.psync[264].item()) != 0:
+            print("[arcvae_hip] persistent forward sweep not usable on this device (blocks per XCD != 32?): "
+                  "falling back to per-step launches")
+            os.environ["ARCVAE_PERSIST"] = "0"
+            ws.psync.zero_()
 
     def set_hyper(self, ws: Workspace, **kw) -> None:
         h = dict(self.hyper_host)
@@ -605,26 +643,26 @@ class StepEngine:
             run("dec_bwd", dec_bwd, self.side)
             self.ev_dec_bwd.record(self.side)
 
-    def _enc_fwd(self, ws: Workspace, backward: bool) -> None:
+    def _enc_fwd(self, ws: Workspace, backward: bool, start_signal=None) -> None:
         if backward:
             self.enc.grad.zero_()
-        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]))
+        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]), start_signal)
 
-    def enqueue_encoder_forward(self, ws: Workspace, run=_inline, backward: bool = True) -> None:
+    def enqueue_encoder_forward(self, ws: Workspace, run=_inline, backward: bool = True, start_signal=None) -> None:
         """Encoder forward on the current stream; leaves this process's partial latent `stats` (the CE slot
-        stats[2Z+3] is filled later by enqueue_finish)."""
-        run("enc_fwd", lambda: self._enc_fwd(ws, backward), torch.cuda.current_stream())
+        stats[2Z+3] is filled later by enqueue_finish).  start_signal: gate word raised when the sweep starts."""
+        run("enc_fwd", lambda: self._enc_fwd(ws, backward, start_signal), torch.cuda.current_stream())
         self.ev_enc_fwd.record(torch.cuda.current_stream())
 
     def enqueue_backward(self, ws: Workspace, run=_inline, fuse_forward: bool = False, after_first=None,
-                         gates: Optional[Gates] = None) -> None:
+                         gates: Optional[Gates] = None, start_signal=None) -> None:
         """`stats[:2Z+3]` holds GLOBAL sums (or, with fuse_forward, will: single process): latent loss scalars
         and gradients, then the encoder backward.  Does NOT wait for the decoder."""
         fb = float(self.hyper_host["free_bits"])
 
         def prologue():
             if fuse_forward:
-                self._enc_fwd(ws, True)
+                self._enc_fwd(ws, True, start_signal)
             latent_loss(ws, self.d, fb, True)
 
         # the tail chunk's token-table half goes to the SIDE stream: the decoder finished long ago and, unlike a
@@ -677,13 +715,18 @@ class StepEngine:
             def grun(key, fn, stream, _run=run):             # gated segments are recorded under their own names
                 _run(f"gated:{key}", fn, stream)
 
-            g.signal(g.P, 1)                                 # signal #1: the input copies are done (plain launch)
-            # the decoder's Adam update rides at the end of its own segment (its gradients are complete ~1 ms
-            # before the encoder's): one launch less in the exposed tail of the step
-            self.enqueue_decoder(ws, global_rows, grun, wait_current=False, split_events=False, gate=(g, nc < 2),
-                                 adam_lr=lr if update else None)
-            # encoder forward + loss + dcomb + first sweep chunk as ONE segment (no seam between the sweeps)
-            self.enqueue_backward(ws, grun, gates=g, fuse_forward=True)
+            # Signal #1 ("inputs ready": releases the decoder on side) is raised by the forward sweep when it starts.
+            # The main segment -- encoder forward + loss + dcomb + the whole BPTT chain, no seam in it -- is enqueued
+            # first, the decoder right behind it (in the first, eager step the decoder's gate could otherwise be
+            # waited for before its signal exists; with the persistent sweep its blocks should also be resident before
+            # the decoder's GEMMs fill the CUs).  The decoder's Adam update rides at the end of its own segment (its
+            # gradients are complete ~1 ms before the encoder's): one launch less in the exposed tail of the step.
+            def dec_after_main():
+                self.enqueue_decoder(ws, global_rows, grun, wait_current=False, split_events=False, gate=(g, nc < 2),
+                                     adam_lr=lr if update else None)
+
+            self.enqueue_backward(ws, grun, gates=g, fuse_forward=True, after_first=dec_after_main,
+                                  start_signal=g.word(g.P))
             self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False, gates=g)
             return
         self.side.wait_stream(main)                          # the decoder only has to follow the input copies
@@ -699,8 +742,10 @@ class StepEngine:
         ws = self.workspace(B, T, train=False)
         self.set_hyper(ws, **hyper)
         self.load_inputs(ws, x, cond, eps, coins)
-        self.enqueue_decoder(ws, B, backward=False)
+        # encoder first: the blocks of a persistent sweep should be resident before the decoder's GEMMs fill the CUs
+        self.side.wait_stream(torch.cuda.current_stream())
         self.enqueue_encoder_forward(ws, backward=False)
+        self.enqueue_decoder(ws, B, backward=False, wait_current=False)
         latent_loss(ws, self.d, float(self.hyper_host["free_bits"]), False)
         self.enqueue_recon(ws)
         call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())

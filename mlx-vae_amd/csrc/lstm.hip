@@ -705,6 +705,247 @@ inline bool choose_step2(int B) {
     return B >= 256;
 }
 
+
+// ---- persistent forward sweep (latency regime) ---------------------------------------------------------------------
+// One launch for the whole forward wavefront instead of T + L - 1 dependent launches.  What makes it cheaper than the
+// launches (which pay a ~1.6 us seam plus a cold L2 -- the L2s are invalidated at every kernel boundary -- per step)
+// is the PARTITION: the batch rows are split over the 8 XCDs, so a row's recurrence lives in ONE XCD from the first
+// step to the last.  h_{t-1} is then produced and consumed under one L2: stores are write-through to that L2, loads
+// that bypass L1 see them, no fence, no cross-XCD traffic.  The 32 CUs of an XCD split the 4H gate columns, keep their
+// slice of every weight matrix stationary in LDS (default shape: 3 x 32 KB), and meet once per tick at a barrier that
+// is one 128-B flag line in their own L2 (0.44 us per tick measured; a chip-wide barrier costs 4-7).
+// tools/probe_persist.hip: 2.67 us per tick for the default shape against 4.85 us per launch.
+//
+// Block roles are taken at run time: a block reads its XCC id and draws a slot from that XCD's counter (the dispatcher
+// deals blocks round-robin over the XCDs; with one block per CU -- the LDS footprint forces that -- every XCD receives
+// exactly 32).  Every spin is bounded; a block that gives up raises sync[PS_ERR] and all blocks drain.
+// Shapes: H = 128 * NT (NT = 1..3), L <= 4, ceil(B / 8) <= 16 rows per XCD, weight slices within LDS.
+constexpr int PS_FLAGS = 0, PS_CNT = 256, PS_ERR = 264, PS_WORDS = 272;
+struct PersistArgs {
+    const int32_t* x_tb;
+    const float* table0;
+    const float* bias[ARCVAE_MAX_LAYERS];   // l >= 1
+    const float* wt;                         // k-chunk-major weights [(2L-1)][H/16][4H][16]: Wh_l at l, Wx_l at L+l-1
+    float* hseq;
+    float* cseq;
+    float* gseq;
+    unsigned* sync;                          // PS_WORDS words, zeroed before the launch
+    unsigned* start_signal;                  // or null: += 1 once, when the sweep starts
+    unsigned long long* trace;               // or null: {start, end} per tick of block (xcc 0, role 0)
+    int B, T, H, V, RX, prio;
+};
+
+__device__ __forceinline__ unsigned ps_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+
+template <int NT, int LL>
+__global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
+    constexpr int CW = 16 * NT;          // gate columns per CU
+    constexpr int UW = 4 * NT;           // hidden units per CU
+    constexpr int NCH = 8 * NT;          // 16-wide k-chunks of a source (H / 16)
+    constexpr int CHW = NCH / 4;         // chunks per wave (K split over the 4 waves)
+    constexpr int S = 2 * LL - 1;        // weight matrices
+    constexpr int TPL = 256 / LL;        // epilogue threads per layer
+    constexpr int MAXP = (16 * UW + TPL - 1) / TPL;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;                                 // [S][NCH][CW][16]
+    float* red = lds + S * NCH * CW * 16;            // [4 waves][LL][16][CW]
+    __shared__ unsigned s_role, s_xcc, s_ok;
+    arcvae_set_prio(a.prio);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, T = a.T, H = a.H, G = 4 * a.H, RX = a.RX;
+    if (tid == 0) {
+        s_xcc = ps_xcc_id();
+        s_role = atomicAdd(a.sync + PS_CNT + (s_xcc & 7), 1u);
+        s_ok = 1;
+        if (blockIdx.x == 0 && a.start_signal)
+            __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned xcc = s_xcc, role = s_role;
+    if (xcc >= 8 || role >= 32) {                    // no slot on this XCD: the others will time out and drain
+        if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
+        return;
+    }
+    const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
+    // stationary weights: permuted rows [role*CW, +CW) of every source
+    {
+        const long wsz = (long)H * G;
+        for (int i = tid; i < S * NCH * CW * 4; i += 256) {
+            const int s = i / (NCH * CW * 4), rem = i - s * (NCH * CW * 4);
+            const int kc = rem / (CW * 4), c4 = rem - kc * (CW * 4);
+            reinterpret_cast<float4*>(wl)[i] =
+                *reinterpret_cast<const float4*>(a.wt + s * wsz + ((long)kc * G + role * CW) * 16 + c4 * 4);
+        }
+    }
+    __syncthreads();
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    const int row0 = xcc * RX;
+    const int arow = min(row0 + min(r, RX - 1), B - 1);         // tile rows beyond this XCD's rows repeat the last one
+    // epilogue ownership: layer el, pairs p = tl + i*TPL of the RX x UW (row, unit) pairs of this block
+    const int el = min(tid / TPL, LL - 1), tl = tid - el * TPL;
+    const bool eactive = tid < LL * TPL;
+    float cst[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) cst[i] = 0.f;
+    const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
+    unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
+    const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
+
+    for (int s = 0; s < T + LL - 1; ++s) {
+        // The additive terms of this tick's gates (layer 0: token -> row of table0, a dependent pair of loads; else the
+        // bias) do not depend on the previous tick: request them BEFORE waiting at the barrier.
+        float pv[MAXP][4];
+        {
+            const int t = s - el;
+            if (eactive && t >= 0 && t < T) {
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i) {
+                    const int p = tl + i * TPL;
+                    if (p < RX * UW) {
+                        const int erow = p / UW, ul = p - erow * UW;
+                        const int b = min(row0 + erow, B - 1);
+                        const int unit = role * UW + ul;
+                        const float* pre;
+                        if (el == 0) {
+                            int tk = a.x_tb[(long)t * B + b];
+                            tk = min(max(tk, 0), a.V - 1);
+                            pre = a.table0 + (long)tk * G;
+                        } else {
+                            pre = a.bias[el];
+                        }
+                        pv[i][0] = pre[unit]; pv[i][1] = pre[H + unit]; pv[i][2] = pre[2 * H + unit]; pv[i][3] = pre[3 * H + unit];
+                    }
+                }
+            }
+        }
+        if (s > 0) {   // every CU of my XCD has published tick s-1
+            if (wave == 0) {
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                   : (unsigned)s;
+                    if (__all((int)(v - (unsigned)s) >= 0)) break;
+                    if (++spins > 4000000u || __hip_atomic_load(a.sync + PS_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        if (lane == 0) { atomicAdd(a.sync + PS_ERR, 1u); s_ok = 0; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (!s_ok) return;
+        }
+        if (tr) a.trace[2 * s] = wall_clock64();
+        // ---- A operands: rows of my XCD from the slabs the previous tick wrote (L1-bypassing loads)
+        f32x4 fx[LL][CHW], fh[LL][CHW];
+#pragma unroll
+        for (int l = 0; l < LL; ++l) {
+            const int t = s - l;
+            const bool act = t >= 0 && t < T;
+            if (act && l > 0) {
+                const float* p = a.hseq + (l - 1) * lH + (long)t * sH + (long)arow * H + wave * CHW * 16 + q4;
+#pragma unroll
+                for (int c = 0; c < CHW; ++c) fx[l][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
+            }
+            if (act && t > 0) {
+                const float* p = a.hseq + l * lH + (long)(t - 1) * sH + (long)arow * H + wave * CHW * 16 + q4;
+#pragma unroll
+                for (int c = 0; c < CHW; ++c) fh[l][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
+            }
+        }
+        // ---- MFMA: pre-activations of my CW columns, K quarter of this wave, weights from LDS
+#pragma unroll
+        for (int l = 0; l < LL; ++l) {
+            const int t = s - l;
+            if (t < 0 || t >= T) continue;            // block-uniform
+            f32x4 acc[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define PS_SRC(FR, SIDX)                                                                                         \
+            _Pragma("unroll") for (int c = 0; c < CHW; ++c) {                                                    \
+                const int kc = wave * CHW + c;                                                                   \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                 \
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + (((SIDX) * NCH + kc) * CW + 16 * n + r) * 16 + q4); \
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].x, w.x, acc[n], 0, 0, 0);             \
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].y, w.y, acc[n], 0, 0, 0);             \
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].z, w.z, acc[n], 0, 0, 0);             \
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].w, w.w, acc[n], 0, 0, 0);             \
+                }                                                                                                \
+            }
+            if (l > 0) { PS_SRC(fx, LL + l - 1) }
+            if (t > 0) { PS_SRC(fh, l) }
+#undef PS_SRC
+            float* rp = red + ((wave * LL + l) * 16) * CW;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) rp[((lane >> 4) * 4 + reg) * CW + 16 * n + r] = acc[n][reg];
+        }
+        __syncthreads();
+        // ---- cell update of my (row, unit) pairs; c stays in a register from tick to tick.  (Storing the saved gates
+        // and c after the flag, under the next tick's barrier wait, was measured: no gain.)
+        const int te = s - el;
+        if (eactive && te >= 0 && te < T) {
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int p = tl + i * TPL;
+                if (p >= RX * UW) break;
+                const int erow = p / UW, ul = p - erow * UW;
+                const int b = row0 + erow;
+                if (b >= B) continue;
+                const int unit = role * UW + ul;
+                const int cb = erow * CW + 16 * (ul >> 2) + (ul & 3);
+                float v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int o = el * 16 * CW + cb + 4 * g;
+                    v[g] = (red[o] + red[LL * 16 * CW + o]) + (red[2 * LL * 16 * CW + o] + red[3 * LL * 16 * CW + o]);
+                }
+                const float gi = sigmoidf_acc(v[0] + pv[i][0]);
+                const float gf = sigmoidf_acc(v[1] + pv[i][1]);
+                const float gg = tanhf(v[2] + pv[i][2]);
+                const float go = sigmoidf_acc(v[3] + pv[i][3]);
+                const float c = te > 0 ? gf * cst[i] + gi * gg : gi * gg;   // MLX: cell=None at t == 0 -> c = i*g
+                cst[i] = c;
+                const long hb = (long)b * H + unit;
+                a.hseq[el * lH + (long)te * sH + hb] = go * tanhf(c);
+                float* gp = a.gseq + el * lG + (long)te * sG + (long)b * G + unit;
+                gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+                a.cseq[el * lH + (long)te * sH + hb] = c;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): my h stores have reached the L2
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tr) a.trace[2 * s + 1] = wall_clock64();
+    }
+}
+
+template <int NT, int LL>
+void launch_persist(const PersistArgs& a, size_t lds, hipStream_t s) {
+    static bool attr_set = false;   // > 64 KB of dynamic LDS has to be allowed once per kernel (first call: eager step)
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL>), dim3(256), dim3(256), lds, s, a);
+}
+inline size_t persist_lds_bytes(int H, int L) {
+    const int NT = H / 128, CW = 16 * NT;
+    return sizeof(float) * ((size_t)(2 * L - 1) * (H / 16) * CW * 16 + (size_t)4 * L * 16 * CW);
+}
+inline bool persist_shape_ok(int B, int T, int H, int L) {
+    if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return false;
+    if (H % 128 != 0 || H / 128 > 3 || L < 1 || L > 4 || B < 1 || T < 1) return false;
+    if (ceil_div(B, 8) > 16) return false;
+    return persist_lds_bytes(H, L) <= 150 * 1024;
+}
+
 template <int CH>
 void launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(lstm_fwd_step_kernel<CH>, grid, dim3(256), 0, s, a);
@@ -747,6 +988,30 @@ extern "C" int arcvae_set_step_trace(unsigned long long* buf, int cap) {
     return ARCVAE_OK;
 }
 
+// tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz; with wT_bwd also the BPTT layouts of
+// the same weights (keeps that launch off the chain between the sweeps) -- one launch for both when the 2(2L-1) jobs
+// fit (L <= 4)
+static int tile_all_weights(const float* const* Wx, const float* const* Wh, float* wt, float* wT_bwd, int H, int L,
+                            hipStream_t stream) {
+    const long wsz = (long)H * 4 * H;
+    const float* src[32];
+    float* dst[32];
+    int cols[32], mode[32];
+    int n = 0;
+    for (int pass = 0; pass < (wT_bwd ? 2 : 1); ++pass) {
+        float* base = pass == 0 ? wt : wT_bwd;
+        for (int l = 0; l < L; ++l) {
+            src[n] = Wh[l]; dst[n] = base + l * wsz; cols[n] = H; mode[n] = pass; ++n;
+            if (l > 0) { src[n] = Wx[l]; dst[n] = base + (L + l - 1) * wsz; cols[n] = H; mode[n] = pass; ++n; }
+        }
+    }
+    for (int i = 0; i < n; i += 16) {
+        const int rc = arcvae_tile_weights(src + i, dst + i, cols + i, mode + i, n - i < 16 ? n - i : 16, H, stream);
+        if (rc != ARCVAE_OK) return rc;
+    }
+    return ARCVAE_OK;
+}
+
 // Reference: models/encoder.py:98-101 (L stacked nn.LSTM over the full padded sequence, Q3).
 //   x_tb   [T,B] tokens (time-major)          table0 [V,4H] = emb . Wx_0^T + bias_0
 //   Wx[l]  [4H,H] (l >= 1), Wh[l] [4H,H], bias[l] [4H] (l >= 1): HOST arrays of device pointers
@@ -769,24 +1034,9 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
     const long wsz = (long)H * 4 * H;
-    {   // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz; with wT_bwd also the BPTT
-        // layouts of the same weights (keeps that launch off the chain between the sweeps) -- one launch for both
-        // when the 2(2L-1) jobs fit (L <= 4)
-        const float* src[32];
-        float* dst[32];
-        int cols[32], mode[32];
-        int n = 0;
-        for (int pass = 0; pass < (wT_bwd ? 2 : 1); ++pass) {
-            float* base = pass == 0 ? wt : wT_bwd;
-            for (int l = 0; l < L; ++l) {
-                src[n] = Wh[l]; dst[n] = base + l * wsz; cols[n] = H; mode[n] = pass; ++n;
-                if (l > 0) { src[n] = Wx[l]; dst[n] = base + (L + l - 1) * wsz; cols[n] = H; mode[n] = pass; ++n; }
-            }
-        }
-        for (int i = 0; i < n; i += 16) {
-            const int rc = arcvae_tile_weights(src + i, dst + i, cols + i, mode + i, n - i < 16 ? n - i : 16, H, stream);
-            if (rc != ARCVAE_OK) return rc;
-        }
+    {
+        const int rc = tile_all_weights(Wx, Wh, wt, wT_bwd, H, L, stream);
+        if (rc != ARCVAE_OK) return rc;
     }
     int tile_mt = choose_tile_mt(B, H / 32, L);
     const int tile_env = arcvae_env_int("ARCVAE_STEP_TILE", -1);
@@ -830,6 +1080,42 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
         dim3 grid(H / 4, ceil_div(B, 16), nj);
         DISPATCH_CH(H, launch_fwd, a, grid, stream)
     }
+    return arcvae_launch_status();
+}
+
+
+// 1 if arcvae_enc_lstm_forward_persistent supports the shape (and ARCVAE_PERSIST != 0), else 0.
+extern "C" int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L) { return persist_shape_ok(B, T, H, L) ? 1 : 0; }
+
+// The forward sweep of arcvae_enc_lstm_forward as ONE persistent launch (lstm_fwd_persist_kernel) for the latency
+// regime.  Same outputs hseq / cseq / gseq (no k-chunk-major h copy is needed); sync_ws: PS_WORDS (272) u32 of
+// scratch (zeroed here); start_signal (optional): += 1 when the sweep starts.  After the stream has drained,
+// sync_ws[264] != 0 means a block gave up waiting (results invalid: fall back to arcvae_enc_lstm_forward).
+extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
+                                                  const float* const* Wh, const float* const* bias, float* hseq,
+                                                  float* cseq, float* gseq, float* wt, float* wT_bwd,
+                                                  unsigned* sync_ws, unsigned* start_signal, int B, int T, int V,
+                                                  int H, int L, hipStream_t stream) {
+    if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq || !wt || !sync_ws) return ARCVAE_ERR_ARG;
+    if (V <= 0 || !persist_shape_ok(B, T, H, L)) return ARCVAE_ERR_ARG;
+    for (int l = 0; l < L; ++l)
+        if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
+    int rc = tile_all_weights(Wx, Wh, wt, wT_bwd, H, L, stream);
+    if (rc != ARCVAE_OK) return rc;
+    rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS, PS_WORDS, stream);
+    if (rc != ARCVAE_OK) return rc;
+    PersistArgs a;
+    a.x_tb = x_tb; a.table0 = table0; a.wt = wt; a.hseq = hseq; a.cseq = cseq; a.gseq = gseq;
+    for (int l = 0; l < ARCVAE_MAX_LAYERS; ++l) a.bias[l] = (l > 0 && l < L) ? bias[l] : nullptr;
+    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace_slot(0);
+    a.B = B; a.T = T; a.H = H; a.V = V; a.RX = ceil_div(B, 8); a.prio = arcvae_step_prio();
+    const size_t lds = persist_lds_bytes(H, L);
+    const int NT = H / 128;
+#define PS_LAUNCH(N_, L_) launch_persist<N_, L_>(a, lds, stream)
+#define PS_BY_L(N_) switch (L) { case 1: PS_LAUNCH(N_, 1); break; case 2: PS_LAUNCH(N_, 2); break; case 3: PS_LAUNCH(N_, 3); break; default: PS_LAUNCH(N_, 4); break; }
+    if (NT == 1) { PS_BY_L(1) } else if (NT == 2) { PS_BY_L(2) } else { PS_BY_L(3) }
+#undef PS_BY_L
+#undef PS_LAUNCH
     return arcvae_launch_status();
 }
 
