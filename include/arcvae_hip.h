@@ -79,13 +79,20 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
 /* The same forward sweep as ONE persistent launch for the latency regime (H = 128, 256 or 384, L <= 4, B <= 128, weight
  * slices within LDS; arcvae_enc_lstm_persistent_ok says whether a shape qualifies): batch rows partitioned over the 8
  * XCDs, weights stationary in LDS, one flag-line barrier per XCD and tick.  No k-chunk-major h
- * copy is written.  sync_ws: 272 u32 of scratch; sync_ws[264] != 0 afterwards = a block gave up waiting.  start_signal
- * (optional): += 1 when the sweep starts. */
+ * copy is written.  sync_ws: 512 u32 of scratch; sync_ws[500] != 0 afterwards = a block gave up waiting (sticky).
+ * start_signal (optional): += 1 when the sweep starts.  The BPTT counterpart covers ticks [s_begin, s_end) of
+ * arcvae_enc_lstm_backward's schedule per launch (L <= 2, ceil(B/8) * H/32 <= 64); a sweep uses it for all its
+ * chunks or for none (no k-chunk-major dG copy is written). */
 int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
                                        float* gseq, float* wt, float* wT_bwd, unsigned* sync_ws, unsigned* start_signal,
                                        int B, int T, int V, int H, int L, arcvae_stream_t stream);
+int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L);
+int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, const float* dh_top, int ld_dh_top,
+                                        float* dG, float* dcs, float* dxs, const float* wT, unsigned* sync_ws,
+                                        unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
+                                        arcvae_stream_t stream);
 /* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,

@@ -91,7 +91,7 @@ class Workspace:
         self.logvar = torch.empty(B, Z, **f32)
         self.z = torch.empty(B, Z, **f32)
         self.stats = torch.zeros(2 * Z + 4, **f32)
-        self.psync = torch.zeros(272, **i32)     # scratch of the persistent forward sweep (flags, roles, error word)
+        self.psync = torch.zeros(512, **i32)     # scratch of the persistent sweeps (flags, role counters; [500] = error)
         self.scalars = torch.zeros(16, **f32)
         # decoder forward (dense over B*V rows)
         self.tableD = torch.empty(V, G, **f32)
@@ -351,6 +351,12 @@ class EncoderBackwardPlan:
     def sweep(self, s0: int, s1: int, start_signal: Optional[C.c_void_p] = None) -> None:
         # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
+        sig = start_signal if start_signal is not None else C.c_void_p(0)
+        if _lib.load().arcvae_enc_lstm_bwd_persistent_ok(ws.B, ws.T, d.H, d.L) == 1:
+            # latency regime: one persistent launch per chunk (csrc/lstm.hip: lstm_bwd_persist_kernel)
+            call("arcvae_enc_lstm_backward_persistent", ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG),
+                 ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ptr(ws.psync), sig, ws.B, ws.T, d.H, d.L, s0, s1, stream_ptr())
+            return
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
              2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
              0,  # retile = 0: the forward of this step already wrote the BPTT weight layouts
@@ -545,7 +551,7 @@ class StepEngine:
         if self.gates is not None and self.gates.errors() != 0:
             raise _lib.ArcvaeHipError("a device-side gate expired (stream ordering was lost); set ARCVAE_GATES=0")
         for ws in self._ws.values():
-            if int(ws.psync[264].item()) != 0:
+            if int(ws.psync[500].item()) != 0:
                 raise _lib.ArcvaeHipError("the persistent forward sweep gave up waiting (no 32 resident blocks per XCD "
                                           "or a stalled block); set ARCVAE_PERSIST=0")
 
@@ -571,7 +577,7 @@ class StepEngine:
         ws.x_tb.zero_()
         encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]))
         torch.cuda.synchronize()
-        if int(ws.psync[264].item()) != 0:
+        if int(ws.psync[500].item()) != 0:
             print("[arcvae_hip] persistent forward sweep not usable on this device (blocks per XCD != 32?): "
                   "falling back to per-step launches")
             os.environ["ARCVAE_PERSIST"] = "0"

@@ -720,7 +720,8 @@ inline bool choose_step2(int B) {
 // deals blocks round-robin over the XCDs; with one block per CU -- the LDS footprint forces that -- every XCD receives
 // exactly 32).  Every spin is bounded; a block that gives up raises sync[PS_ERR] and all blocks drain.
 // Shapes: H = 128 * NT (NT = 1..3), L <= 4, ceil(B / 8) <= 16 rows per XCD, weight slices within LDS.
-constexpr int PS_FLAGS = 0, PS_CNT = 256, PS_ERR = 264, PS_WORDS = 272;
+constexpr int PS_FLAGS = 0, PS_CNT = 256, PS_WORDS = 272;   // re-armed (zeroed) before every sweep: flags, role counters
+constexpr int PS_ERR = 500;                                  // sticky error word, outside the re-armed range (buffer: 512 words)
 struct PersistArgs {
     const int32_t* x_tb;
     const float* table0;
@@ -846,6 +847,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
         for (int l = 0; l < LL; ++l) {
             const int t = s - l;
             const bool act = t >= 0 && t < T;
+            // (tile rows beyond this XCD's RX rows repeat its last row; masking those loads off was measured: slower)
             if (act && l > 0) {
                 const float* p = a.hseq + (l - 1) * lH + (long)t * sH + (long)arow * H + wave * CHW * 16 + q4;
 #pragma unroll
@@ -944,6 +946,224 @@ inline bool persist_shape_ok(int B, int T, int H, int L) {
     if (H % 128 != 0 || H / 128 > 3 || L < 1 || L > 4 || B < 1 || T < 1) return false;
     if (ceil_div(B, 8) > 16) return false;
     return persist_lds_bytes(H, L) <= 150 * 1024;
+}
+
+
+// ---- persistent BPTT sweep (latency regime) ------------------------------------------------------------------------
+// The BPTT wavefront with the same row partition as lstm_fwd_persist_kernel: XCD g owns rows [g*RX, (g+1)*RX), its 32
+// CUs split the H hidden units, the W^T slices are stationary in LDS, the per-tick barrier is the XCD's flag line.
+// One launch covers a CHUNK of the sweep ([s_begin, s_end) of the T + 2(L-1) ticks of arcvae_enc_lstm_backward's
+// schedule): the kernel boundary between chunks is what writes the gate gradients back from the XCD's L2 for the
+// weight-gradient GEMMs that overlap the sweep on other XCDs, and what carries the chunk signal.  State that crosses a
+// tick stays on chip (dc*f of a (layer, row, unit) in a register of the thread that owns it, dX in LDS); it is also
+// written to the dcs / dxs rings every tick so that the next chunk can pick it up.
+// Slots (fixed thread groups of 64): cell(l) -> LL-1-l, xproj(l) -> LL + l.  L <= 2, RX * UW <= 64 pairs per slot.
+struct PersistBwdArgs {
+    const float* wT;          // k-chunk-major transposed weights [(2L-1)][4H/16][H][16]: WhT_l at l, WxT_{l+1} at L + l
+    const float* cseq;
+    const float* gseq;        // saved gates (dG may alias it)
+    const float* dh_top;
+    float* dG;
+    float* dcs;               // [L][RS][B][H] ring
+    float* dxs;               // [L][RS][B][H] ring
+    unsigned* sync;           // PS_WORDS words; flags hold the global tick index, role counters per chunk launch
+    unsigned* start_signal;
+    unsigned long long* trace;
+    int B, T, H, RX, RS, ld_dh_top, s_begin, s_end, cnt_off, prio;
+};
+
+template <int NT, int LL>
+__global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a) {
+    constexpr int UW = 4 * NT;           // hidden units per CU
+    constexpr int NCHB = 32 * NT;        // 16-wide k-chunks of a source (4H / 16)
+    constexpr int CHB = NCHB / 4;        // chunks per wave
+    constexpr int S = 2 * LL - 1;        // sources = slots
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;                                  // [S][NCHB][UW][16]
+    float* red = wl + S * NCHB * UW * 16;             // [4 waves][S][16][16]
+    float* dxl = red + 4 * S * 256;                   // [2][LL][64]  dX of the previous / this tick
+    __shared__ unsigned s_role, s_xcc, s_ok;
+    arcvae_set_prio(a.prio);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, T = a.T, H = a.H, G = 4 * a.H, RX = a.RX, RS = a.RS;
+    if (tid == 0) {
+        s_xcc = ps_xcc_id();
+        s_role = atomicAdd(a.sync + PS_CNT + a.cnt_off + (s_xcc & 7), 1u);
+        s_ok = 1;
+        if (blockIdx.x == 0 && a.start_signal)
+            __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned xcc = s_xcc, role = s_role;
+    if (xcc >= 8 || role >= 32) {
+        if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
+        return;
+    }
+    const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
+    {
+        const long wsz = (long)H * G;
+        for (int i = tid; i < S * NCHB * UW * 4; i += 256) {
+            const int sidx = i / (NCHB * UW * 4), rem = i - sidx * (NCHB * UW * 4);
+            const int kc = rem / (UW * 4), c4 = rem - kc * (UW * 4);
+            // slot -> weight matrix: cell(l) (slot LL-1-l) uses WhT_l, xproj(l) (slot LL+l) uses WxT_{l+1} at LL + l
+            const int widx = sidx < LL ? (LL - 1 - sidx) : sidx;
+            reinterpret_cast<float4*>(wl)[i] =
+                *reinterpret_cast<const float4*>(a.wT + widx * wsz + ((long)kc * H + role * UW) * 16 + c4 * 4);
+        }
+    }
+    __syncthreads();
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    const int row0 = xcc * RX;
+    const int arow = min(row0 + min(r, RX - 1), B - 1);
+    const int ub = min(r, UW - 1);
+    const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
+    // epilogue ownership: slot = tid >> 6 (threads of slots >= S idle), pair p = tid & 63
+    const int slot = tid >> 6, p = tid & 63;
+    const bool eact = slot < S && p < RX * UW && row0 + p / UW < B;
+    const int erow = p / UW, ul = p - erow * UW;
+    const int eb = min(row0 + erow, B - 1);
+    const int unit = role * UW + ul;
+    const bool is_cell = slot < LL;
+    const int el = is_cell ? (LL - 1 - slot) : (slot - LL);   // layer of the slot
+    const long hb = (long)eb * H + unit;
+    float dcst = 0.f;                                  // dc_{t+1} * f_{t+1} of my (layer, row, unit)
+    unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
+    const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
+
+    for (int s = a.s_begin; s < a.s_end; ++s) {
+        // this tick's job of my slot
+        const int skew = 2 * (LL - 1 - el);
+        const int t = is_cell ? T - 1 - (s - skew) : T - 1 - (s + 1 - skew);
+        const bool jact = t >= 0 && t < T;
+        // forward values of the cell epilogue (static): requested before the barrier wait
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c_v = 0.f, cprev_v = 0.f, ext_v = 0.f;
+        if (eact && is_cell && jact) {
+            const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb * G + unit;
+            gi = gp[0]; gf = gp[H]; gg = gp[2 * H]; go = gp[3 * H];
+            c_v = a.cseq[el * lH + (long)t * sH + hb];
+            if (t > 0) cprev_v = a.cseq[el * lH + (long)(t - 1) * sH + hb];
+            if (el == LL - 1 && t == T - 1) ext_v = a.dh_top[(long)eb * a.ld_dh_top + unit];
+            if (s == a.s_begin) {   // state of the previous chunk (or none at the very first tick of a layer)
+                dcst = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb] : 0.f;
+                if (el < LL - 1) ext_v = a.dxs[((long)el * RS + (t % RS)) * sH + hb];
+            }
+        }
+        if (s > 0) {   // every CU of my XCD has published tick s-1 (flags carry the global tick index)
+            if (wave == 0) {
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                   : (unsigned)s;
+                    if (__all((int)(v - (unsigned)s) >= 0)) break;
+                    if (++spins > 4000000u || __hip_atomic_load(a.sync + PS_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        if (lane == 0) { atomicAdd(a.sync + PS_ERR, 1u); s_ok = 0; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (!s_ok) return;
+        }
+        if (tr) a.trace[2 * s] = wall_clock64();
+        // ---- contractions of the S slots, one after the other, the next slot's operand loads in flight behind the MFMAs
+        const float* srcp[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const bool cellj = j < LL;
+            const int lj = cellj ? (LL - 1 - j) : (j - LL);
+            const int skj = 2 * (LL - 1 - lj);
+            const int tj = cellj ? T - 1 - (s - skj) : T - 1 - (s + 1 - skj);
+            const float* pj = nullptr;
+            if (tj >= 0 && tj < T) {
+                if (cellj) { if (tj < T - 1) pj = a.dG + lj * lG + (long)(tj + 1) * sG; }   // dG^l_{t+1}
+                else pj = a.dG + (lj + 1) * lG + (long)tj * sG;                                // dG^{l+1}_{tx}
+            }
+            srcp[j] = pj;
+        }
+        f32x4 fa[2][CHB];
+        if (srcp[0]) {
+            const float* pa = srcp[0] + (long)arow * G + wave * CHB * 16 + q4;
+#pragma unroll
+            for (int c = 0; c < CHB; ++c) fa[0][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa + c * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            if (j + 1 < S && srcp[j + 1 < S ? j + 1 : j]) {
+                const float* pa = srcp[j + 1 < S ? j + 1 : j] + (long)arow * G + wave * CHB * 16 + q4;
+#pragma unroll
+                for (int c = 0; c < CHB; ++c)
+                    fa[(j + 1) & 1][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa + c * 16));
+            }
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (srcp[j]) {
+#pragma unroll
+                for (int c = 0; c < CHB; ++c) {
+                    const int kc = wave * CHB + c;
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + ((j * NCHB + kc) * UW + ub) * 16 + q4);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].x, w.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].y, w.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].z, w.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].w, w.w, acc, 0, 0, 0);
+                }
+            }
+            float* rp = red + (wave * S + j) * 256;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) rp[((lane >> 4) * 4 + reg) * 16 + r] = acc[reg];
+        }
+        __syncthreads();
+        // ---- epilogue of my (slot, row, unit)
+        if (eact && jact) {
+            const int o = slot * 256 + erow * 16 + ul;
+            float dh = (red[o] + red[S * 256 + o]) + (red[2 * S * 256 + o] + red[3 * S * 256 + o]);
+            if (!is_cell) {                                     // dX_l[tx]: consumed by cell(l, tx) at the next tick
+                dxl[((s + 1) & 1) * LL * 64 + el * 64 + p] = dh;
+                a.dxs[((long)el * RS + (t % RS)) * sH + hb] = dh;
+            } else {
+                if (el < LL - 1 && s != a.s_begin) ext_v = dxl[(s & 1) * LL * 64 + el * 64 + p];
+                dh += ext_v;
+                const float tc = tanhf(c_v);
+                const float d_o = dh * tc * go * (1.f - go);
+                const float dc = dh * go * (1.f - tc * tc) + dcst;
+                const float d_i = dc * gg * gi * (1.f - gi);
+                const float d_f = t > 0 ? dc * cprev_v * gf * (1.f - gf) : 0.f;
+                const float d_g = dc * gi * (1.f - gg * gg);
+                dcst = dc * gf;
+                a.dcs[((long)el * RS + (t % RS)) * sH + hb] = dcst;
+                float* dp = a.dG + el * lG + (long)t * sG + (long)eb * G + unit;
+                dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my dG stores have reached the XCD's L2
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tr) a.trace[2 * s + 1] = wall_clock64();
+    }
+}
+
+template <int NT, int LL>
+void launch_persist_bwd(const PersistBwdArgs& a, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_kernel<NT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_persist_kernel<NT, LL>), dim3(256), dim3(256), lds, s, a);
+}
+inline size_t persist_bwd_lds_bytes(int H, int L) {
+    const int NT = H / 128, UW = 4 * NT, S = 2 * L - 1;
+    return sizeof(float) * ((size_t)S * (4 * H / 16) * UW * 16 + (size_t)4 * S * 256 + (size_t)2 * L * 64);
+}
+inline bool persist_bwd_shape_ok(int B, int T, int H, int L) {
+    // Opt-in (ARCVAE_PERSIST_BWD=1): measured SLOWER than the launches at the default shape (tick 5.4 us alone, 7-8 us
+    // beside the weight-gradient GEMMs, against 5.0 / 5.4-6.3 us per launch; step 1.64 vs 1.40 ms) -- the operand of a
+    // tick is 4x the forward's (96 KB per CU, three dependent load/MFMA rounds) and the 8 x 8 tiles use a quarter of the
+    // 16 x 16 MFMA.  Kept: parity-green, and the base for a version that packs two sources into one tile.
+    if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0 || arcvae_env_int("ARCVAE_PERSIST_BWD", 0) == 0) return false;
+    if (H % 128 != 0 || H / 128 > 3 || L < 1 || L > 2 || B < 1 || T < 1) return false;
+    if (ceil_div(B, 8) * (H / 32) > 64) return false;      // one (row, unit) pair per thread of a slot
+    return persist_bwd_lds_bytes(H, L) <= 150 * 1024;
 }
 
 template <int CH>
@@ -1088,9 +1308,9 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
 extern "C" int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L) { return persist_shape_ok(B, T, H, L) ? 1 : 0; }
 
 // The forward sweep of arcvae_enc_lstm_forward as ONE persistent launch (lstm_fwd_persist_kernel) for the latency
-// regime.  Same outputs hseq / cseq / gseq (no k-chunk-major h copy is needed); sync_ws: PS_WORDS (272) u32 of
-// scratch (zeroed here); start_signal (optional): += 1 when the sweep starts.  After the stream has drained,
-// sync_ws[264] != 0 means a block gave up waiting (results invalid: fall back to arcvae_enc_lstm_forward).
+// regime.  Same outputs hseq / cseq / gseq (no k-chunk-major h copy is needed); sync_ws: 512 u32 of scratch (the first
+// 272 are re-armed here); start_signal (optional): += 1 when the sweep starts.  After the stream has drained,
+// sync_ws[500] != 0 means a block gave up waiting (results invalid: fall back to arcvae_enc_lstm_forward).
 extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                                   const float* const* Wh, const float* const* bias, float* hseq,
                                                   float* cseq, float* gseq, float* wt, float* wT_bwd,
@@ -1116,6 +1336,44 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
     if (NT == 1) { PS_BY_L(1) } else if (NT == 2) { PS_BY_L(2) } else { PS_BY_L(3) }
 #undef PS_BY_L
 #undef PS_LAUNCH
+    return arcvae_launch_status();
+}
+
+
+// 1 if arcvae_enc_lstm_backward_persistent supports the shape (and ARCVAE_PERSIST / ARCVAE_PERSIST_BWD != 0).
+extern "C" int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L) { return persist_bwd_shape_ok(B, T, H, L) ? 1 : 0; }
+
+// Ticks [s_begin, s_end) of the BPTT wavefront of arcvae_enc_lstm_backward as ONE persistent launch
+// (lstm_bwd_persist_kernel).  Same schedule, same outputs dG / dcs / dxs (no k-chunk-major dG copy is written, so a
+// sweep must use this entry point for all its chunks or for none); the BPTT weight layouts wT must be current (written
+// by the forward); sync_ws as for the forward (its flags are re-armed when s_begin == 0).
+extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, const float* dh_top,
+                                                   int ld_dh_top, float* dG, float* dcs, float* dxs, const float* wT,
+                                                   unsigned* sync_ws, unsigned* start_signal, int B, int T, int H,
+                                                   int L, int s_begin, int s_end, hipStream_t stream) {
+    if (!cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !wT || !sync_ws) return ARCVAE_ERR_ARG;
+    if (!persist_bwd_shape_ok(B, T, H, L) || ld_dh_top < H) return ARCVAE_ERR_ARG;
+    const int S = T + 2 * (L - 1);
+    if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
+    static int chunk_no = 0;   // role counters: a fresh set of 8 words per chunk launch of a sweep (zeroed at s_begin == 0)
+    if (s_begin == 0) {
+        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+        if (rc != ARCVAE_OK) return rc;
+        chunk_no = 0;
+    }
+    if (chunk_no >= 8) return ARCVAE_ERR_ARG;
+    PersistBwdArgs a;
+    a.wT = wT; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
+    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace_slot(g_trace_cap / 2);
+    a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
+    a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
+    a.cnt_off = chunk_no == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_no - 1);   // chunk 0: words 256..263, then 272..
+    ++chunk_no;
+    const size_t lds = persist_bwd_lds_bytes(H, L);
+    const int NT = H / 128;
+#define PB_BY_L(N_) if (L == 1) launch_persist_bwd<N_, 1>(a, lds, stream); else launch_persist_bwd<N_, 2>(a, lds, stream);
+    if (NT == 1) { PB_BY_L(1) } else if (NT == 2) { PB_BY_L(2) } else { PB_BY_L(3) }
+#undef PB_BY_L
     return arcvae_launch_status();
 }
 

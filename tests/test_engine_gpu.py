@@ -295,3 +295,34 @@ def test_default_model_large_batches_kernel_families_agree(B, monkeypatch):
     assert np.all(np.isfinite(a[0])) and np.allclose(a[0], b[0], rtol=2e-5, atol=1e-6), (a[0], b[0])
     assert rel_err(a[2], b[2]) < 1e-5
     assert rel_err(a[1], b[1]) < 1e-4
+
+
+@pytest.mark.parametrize("env", [{"ARCVAE_PERSIST": "0"}, {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "1"}])
+@pytest.mark.parametrize("H,L,B,T,C", [(128, 2, 20, 9, 1), (128, 1, 33, 7, 2), (256, 2, 64, 12, 1), (384, 1, 9, 5, 1)])
+def test_persistent_sweeps_and_their_fallback(env, H, L, B, T, C, monkeypatch):
+    """The persistent per-XCD sweeps (lstm_fwd_persist_kernel: default; lstm_bwd_persist_kernel: opt-in) and the
+    per-step launches they replace, on shapes inside the persistent kernels' range: ragged row groups (B not a
+    multiple of 8), one and two layers, every NT = H / 128, BPTT in chunks.  Same bar: 1e-4 against the fp64 oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    for k in ("mu", "logvar"):
+        assert rel_err(out[k].cpu().numpy(), vals[k]) < TOL, k
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+    assert not bad, bad
