@@ -12,7 +12,7 @@ from typing import Iterable, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libarcvae_hip.so")
+LIB_PATH = os.environ.get("ARCVAE_HIP_LIB", os.path.join(_HERE, "libarcvae_hip.so"))  # override: A/B of two builds
 
 GEMM_ACCUMULATE = 1
 GEMM_TANH = 2
