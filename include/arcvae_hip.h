@@ -76,7 +76,7 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
                              float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,
                              int s_end, int retile, unsigned* start_signal /* optional: += 1 when the first launch of
                              this call starts (all earlier work of the stream is complete) */, arcvae_stream_t stream);
-/* The same forward sweep as ONE persistent launch for the latency regime (H = 128, 256 or 384, L <= 4, B <= 128, weight
+/* The same forward sweep as ONE persistent launch for the latency regime (H = 128, 256 or 384, L <= 4, B <= 256, weight
  * slices within LDS; arcvae_enc_lstm_persistent_ok says whether a shape qualifies): batch rows partitioned over the 8
  * XCDs, weights stationary in LDS, one flag-line barrier per XCD and tick.  No k-chunk-major h
  * copy is written.  sync_ws: 512 u32 of scratch; sync_ws[500] != 0 afterwards = a block gave up waiting (sticky).

@@ -742,7 +742,7 @@ __device__ __forceinline__ unsigned ps_xcc_id() {
     return v & 0xf;
 }
 
-template <int NT, int LL>
+template <int NT, int LL, int RT>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
 __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     constexpr int CW = 16 * NT;          // gate columns per CU
     constexpr int UW = 4 * NT;           // hidden units per CU
@@ -750,10 +750,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     constexpr int CHW = NCH / 4;         // chunks per wave (K split over the 4 waves)
     constexpr int S = 2 * LL - 1;        // weight matrices
     constexpr int TPL = 256 / LL;        // epilogue threads per layer
-    constexpr int MAXP = (16 * UW + TPL - 1) / TPL;
+    constexpr int MAXP = (16 * RT * UW + TPL - 1) / TPL;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                 // [S][NCH][CW][16]
-    float* red = lds + S * NCH * CW * 16;            // [4 waves][LL][16][CW]
+    float* red = lds + S * NCH * CW * 16;            // [4 waves][LL][16*RT][CW]
+    constexpr int RW = LL * 16 * RT * CW;            // floats per wave in red
     __shared__ unsigned s_role, s_xcc, s_ok;
     arcvae_set_prio(a.prio);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -785,7 +786,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     __syncthreads();
     const int r = lane & 15, q4 = (lane >> 4) * 4;
     const int row0 = xcc * RX;
-    const int arow = min(row0 + min(r, RX - 1), B - 1);         // tile rows beyond this XCD's rows repeat the last one
+    int arow[RT];                                               // tile rows beyond this XCD's rows repeat the last one
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) arow[rt] = min(row0 + min(16 * rt + r, RX - 1), B - 1);
     // epilogue ownership: layer el, pairs p = tl + i*TPL of the RX x UW (row, unit) pairs of this block
     const int el = min(tid / TPL, LL - 1), tl = tid - el * TPL;
     const bool eactive = tid < LL * TPL;
@@ -842,21 +845,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
         }
         if (tr) a.trace[2 * s] = wall_clock64();
         // ---- A operands: rows of my XCD from the slabs the previous tick wrote (L1-bypassing loads)
-        f32x4 fx[LL][CHW], fh[LL][CHW];
+        f32x4 fx[LL][RT][CHW], fh[LL][RT][CHW];
 #pragma unroll
         for (int l = 0; l < LL; ++l) {
             const int t = s - l;
             const bool act = t >= 0 && t < T;
             // (tile rows beyond this XCD's RX rows repeat its last row; masking those loads off was measured: slower)
-            if (act && l > 0) {
-                const float* p = a.hseq + (l - 1) * lH + (long)t * sH + (long)arow * H + wave * CHW * 16 + q4;
 #pragma unroll
-                for (int c = 0; c < CHW; ++c) fx[l][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
-            }
-            if (act && t > 0) {
-                const float* p = a.hseq + l * lH + (long)(t - 1) * sH + (long)arow * H + wave * CHW * 16 + q4;
+            for (int rt = 0; rt < RT; ++rt) {
+                if (act && l > 0) {
+                    const float* p = a.hseq + (l - 1) * lH + (long)t * sH + (long)arow[rt] * H + wave * CHW * 16 + q4;
 #pragma unroll
-                for (int c = 0; c < CHW; ++c) fh[l][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
+                    for (int c = 0; c < CHW; ++c)
+                        fx[l][rt][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
+                }
+                if (act && t > 0) {
+                    const float* p = a.hseq + l * lH + (long)(t - 1) * sH + (long)arow[rt] * H + wave * CHW * 16 + q4;
+#pragma unroll
+                    for (int c = 0; c < CHW; ++c)
+                        fh[l][rt][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
+                }
             }
         }
         // ---- MFMA: pre-activations of my CW columns, K quarter of this wave, weights from LDS
@@ -864,28 +872,35 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
         for (int l = 0; l < LL; ++l) {
             const int t = s - l;
             if (t < 0 || t >= T) continue;            // block-uniform
-            f32x4 acc[NT];
+            f32x4 acc[RT][NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define PS_SRC(FR, SIDX)                                                                                         \
             _Pragma("unroll") for (int c = 0; c < CHW; ++c) {                                                    \
                 const int kc = wave * CHW + c;                                                                   \
                 _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                 \
                     const f32x4 w = *reinterpret_cast<const f32x4*>(wl + (((SIDX) * NCH + kc) * CW + 16 * n + r) * 16 + q4); \
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].x, w.x, acc[n], 0, 0, 0);             \
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].y, w.y, acc[n], 0, 0, 0);             \
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].z, w.z, acc[n], 0, 0, 0);             \
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][c].w, w.w, acc[n], 0, 0, 0);             \
+                    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                          \
+                        acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][rt][c].x, w.x, acc[rt][n], 0, 0, 0); \
+                        acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][rt][c].y, w.y, acc[rt][n], 0, 0, 0); \
+                        acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][rt][c].z, w.z, acc[rt][n], 0, 0, 0); \
+                        acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][rt][c].w, w.w, acc[rt][n], 0, 0, 0); \
+                    }                                                                                            \
                 }                                                                                                \
             }
             if (l > 0) { PS_SRC(fx, LL + l - 1) }
             if (t > 0) { PS_SRC(fh, l) }
 #undef PS_SRC
-            float* rp = red + ((wave * LL + l) * 16) * CW;
+            float* rp = red + wave * RW + l * 16 * RT * CW;
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) rp[((lane >> 4) * 4 + reg) * CW + 16 * n + r] = acc[n][reg];
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        rp[(16 * rt + (lane >> 4) * 4 + reg) * CW + 16 * n + r] = acc[rt][n][reg];
         }
         __syncthreads();
         // ---- cell update of my (row, unit) pairs; c stays in a register from tick to tick.  (Storing the saved gates
@@ -904,8 +919,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                 float v[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int o = el * 16 * CW + cb + 4 * g;
-                    v[g] = (red[o] + red[LL * 16 * CW + o]) + (red[2 * LL * 16 * CW + o] + red[3 * LL * 16 * CW + o]);
+                    const int o = el * 16 * RT * CW + cb + 4 * g;
+                    v[g] = (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]);
                 }
                 const float gi = sigmoidf_acc(v[0] + pv[i][0]);
                 const float gf = sigmoidf_acc(v[1] + pv[i][1]);
@@ -927,25 +942,27 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     }
 }
 
-template <int NT, int LL>
+template <int NT, int LL, int RT>
 void launch_persist(const PersistArgs& a, size_t lds, hipStream_t s) {
     static bool attr_set = false;   // > 64 KB of dynamic LDS has to be allowed once per kernel (first call: eager step)
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  150 * 1024);
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL, RT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL>), dim3(256), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL, RT>), dim3(256), dim3(256), lds, s, a);
 }
-inline size_t persist_lds_bytes(int H, int L) {
+inline int persist_row_tiles(int B) { return ceil_div(B, 8) > 16 ? 2 : 1; }
+inline size_t persist_lds_bytes(int B, int H, int L) {
     const int NT = H / 128, CW = 16 * NT;
-    return sizeof(float) * ((size_t)(2 * L - 1) * (H / 16) * CW * 16 + (size_t)4 * L * 16 * CW);
+    return sizeof(float) * ((size_t)(2 * L - 1) * (H / 16) * CW * 16 + (size_t)4 * L * 16 * persist_row_tiles(B) * CW);
 }
+// up to 32 rows per XCD (two MFMA row tiles): B <= 256, i.e. also the 256-row shard of BASELINE.json configs[3]
 inline bool persist_shape_ok(int B, int T, int H, int L) {
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return false;
     if (H % 128 != 0 || H / 128 > 3 || L < 1 || L > 4 || B < 1 || T < 1) return false;
-    if (ceil_div(B, 8) > 16) return false;
-    return persist_lds_bytes(H, L) <= 150 * 1024;
+    if (ceil_div(B, 8) > 32) return false;
+    return persist_lds_bytes(B, H, L) <= 150 * 1024;
 }
 
 
@@ -1329,9 +1346,10 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
     for (int l = 0; l < ARCVAE_MAX_LAYERS; ++l) a.bias[l] = (l > 0 && l < L) ? bias[l] : nullptr;
     a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace_slot(0);
     a.B = B; a.T = T; a.H = H; a.V = V; a.RX = ceil_div(B, 8); a.prio = arcvae_step_prio();
-    const size_t lds = persist_lds_bytes(H, L);
+    const size_t lds = persist_lds_bytes(B, H, L);
     const int NT = H / 128;
-#define PS_LAUNCH(N_, L_) launch_persist<N_, L_>(a, lds, stream)
+    const int RTn = persist_row_tiles(B);
+#define PS_LAUNCH(N_, L_) do { if (RTn == 2) launch_persist<N_, L_, 2>(a, lds, stream); else launch_persist<N_, L_, 1>(a, lds, stream); } while (0)
 #define PS_BY_L(N_) switch (L) { case 1: PS_LAUNCH(N_, 1); break; case 2: PS_LAUNCH(N_, 2); break; case 3: PS_LAUNCH(N_, 3); break; default: PS_LAUNCH(N_, 4); break; }
     if (NT == 1) { PS_BY_L(1) } else if (NT == 2) { PS_BY_L(2) } else { PS_BY_L(3) }
 #undef PS_BY_L
