@@ -989,16 +989,20 @@ struct PersistBwdArgs {
     int B, T, H, RX, RS, ld_dh_top, s_begin, s_end, cnt_off, prio;
 };
 
-template <int NT, int LL>
+template <int NT, int LL, int RT>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
 __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a) {
     constexpr int UW = 4 * NT;           // hidden units per CU
     constexpr int NCHB = 32 * NT;        // 16-wide k-chunks of a source (4H / 16)
     constexpr int CHB = NCHB / 4;        // chunks per wave
     constexpr int S = 2 * LL - 1;        // sources = slots
+    constexpr int NH = RT;               // a source's chunks are loaded in NH pieces (register budget: 2 x RT x CHP float4)
+    constexpr int CHP = CHB / NH;        // chunks per piece
+    constexpr int NP = 16 * RT * UW;     // (row, unit) pairs of a slot
+    constexpr int MAXP = (NP + 63) / 64; // pairs per thread of a slot
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                  // [S][NCHB][UW][16]
-    float* red = wl + S * NCHB * UW * 16;             // [4 waves][S][16][16]
-    float* dxl = red + 4 * S * 256;                   // [2][LL][64]  dX of the previous / this tick
+    float* red = wl + S * NCHB * UW * 16;             // [4 waves][S][16*RT][16]
+    float* dxl = red + 4 * S * 256 * RT;              // [2][LL][NP]  dX of the previous / this tick
     __shared__ unsigned s_role, s_xcc, s_ok;
     arcvae_set_prio(a.prio);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1031,19 +1035,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
     __syncthreads();
     const int r = lane & 15, q4 = (lane >> 4) * 4;
     const int row0 = xcc * RX;
-    const int arow = min(row0 + min(r, RX - 1), B - 1);
+    int arow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) arow[rt] = min(row0 + min(16 * rt + r, RX - 1), B - 1);
     const int ub = min(r, UW - 1);
     const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
-    // epilogue ownership: slot = tid >> 6 (threads of slots >= S idle), pair p = tid & 63
-    const int slot = tid >> 6, p = tid & 63;
-    const bool eact = slot < S && p < RX * UW && row0 + p / UW < B;
-    const int erow = p / UW, ul = p - erow * UW;
-    const int eb = min(row0 + erow, B - 1);
-    const int unit = role * UW + ul;
+    // epilogue ownership: slot = tid >> 6 (threads of slots >= S idle), pairs p = (tid & 63) + 64 i
+    const int slot = tid >> 6, p0 = tid & 63;
     const bool is_cell = slot < LL;
     const int el = is_cell ? (LL - 1 - slot) : (slot - LL);   // layer of the slot
-    const long hb = (long)eb * H + unit;
-    float dcst = 0.f;                                  // dc_{t+1} * f_{t+1} of my (layer, row, unit)
+    float dcst[MAXP];                                  // dc_{t+1} * f_{t+1} of my (layer, row, unit) pairs
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) dcst[i] = 0.f;
     unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
     const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
 
@@ -1051,18 +1054,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
         // this tick's job of my slot
         const int skew = 2 * (LL - 1 - el);
         const int t = is_cell ? T - 1 - (s - skew) : T - 1 - (s + 1 - skew);
-        const bool jact = t >= 0 && t < T;
+        const bool jact = slot < S && t >= 0 && t < T;
         // forward values of the cell epilogue (static): requested before the barrier wait
-        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c_v = 0.f, cprev_v = 0.f, ext_v = 0.f;
-        if (eact && is_cell && jact) {
-            const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb * G + unit;
-            gi = gp[0]; gf = gp[H]; gg = gp[2 * H]; go = gp[3 * H];
-            c_v = a.cseq[el * lH + (long)t * sH + hb];
-            if (t > 0) cprev_v = a.cseq[el * lH + (long)(t - 1) * sH + hb];
-            if (el == LL - 1 && t == T - 1) ext_v = a.dh_top[(long)eb * a.ld_dh_top + unit];
-            if (s == a.s_begin) {   // state of the previous chunk (or none at the very first tick of a layer)
-                dcst = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb] : 0.f;
-                if (el < LL - 1) ext_v = a.dxs[((long)el * RS + (t % RS)) * sH + hb];
+        float gi[MAXP], gf[MAXP], gg[MAXP], go[MAXP], c_v[MAXP], cprev_v[MAXP], ext_v[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            gi[i] = gf[i] = gg[i] = go[i] = c_v[i] = cprev_v[i] = ext_v[i] = 0.f;
+            const int p = p0 + 64 * i;
+            const int erow = p / UW, ul = p - erow * UW;
+            if (is_cell && jact && p < RX * UW && row0 + erow < B) {
+                const int eb = row0 + erow, unit = role * UW + ul;
+                const long hb = (long)eb * H + unit;
+                const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb * G + unit;
+                gi[i] = gp[0]; gf[i] = gp[H]; gg[i] = gp[2 * H]; go[i] = gp[3 * H];
+                c_v[i] = a.cseq[el * lH + (long)t * sH + hb];
+                if (t > 0) cprev_v[i] = a.cseq[el * lH + (long)(t - 1) * sH + hb];
+                if (el == LL - 1 && t == T - 1) ext_v[i] = a.dh_top[(long)eb * a.ld_dh_top + unit];
+                if (s == a.s_begin) {   // state of the previous chunk (or none at the very first tick of a layer)
+                    dcst[i] = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb] : 0.f;
+                    if (el < LL - 1) ext_v[i] = a.dxs[((long)el * RS + (t % RS)) * sH + hb];
+                }
             }
         }
         if (s > 0) {   // every CU of my XCD has published tick s-1 (flags carry the global tick index)
@@ -1083,7 +1094,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
             if (!s_ok) return;
         }
         if (tr) a.trace[2 * s] = wall_clock64();
-        // ---- contractions of the S slots, one after the other, the next slot's operand loads in flight behind the MFMAs
+        // ---- contractions of the S slots, piece by piece, the next piece's operand loads in flight behind the MFMAs
         const float* srcp[S];
 #pragma unroll
         for (int j = 0; j < S; ++j) {
@@ -1098,57 +1109,78 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
             }
             srcp[j] = pj;
         }
-        f32x4 fa[2][CHB];
-        if (srcp[0]) {
-            const float* pa = srcp[0] + (long)arow * G + wave * CHB * 16 + q4;
-#pragma unroll
-            for (int c = 0; c < CHB; ++c) fa[0][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa + c * 16));
+        f32x4 fa[2][RT][CHP];
+#define PB_LOAD(BUF, J, HALF)                                                                                  \
+        if (srcp[J]) {                                                                                         \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                \
+                const float* pa = srcp[J] + (long)arow[rt] * G + (wave * CHB + (HALF) * CHP) * 16 + q4;        \
+                _Pragma("unroll") for (int c = 0; c < CHP; ++c)                                                \
+                    fa[BUF][rt][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa + c * 16)); \
+            }                                                                                                  \
         }
+        PB_LOAD(0, 0, 0)
+        f32x4 acc[RT];
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-            if (j + 1 < S && srcp[j + 1 < S ? j + 1 : j]) {
-                const float* pa = srcp[j + 1 < S ? j + 1 : j] + (long)arow * G + wave * CHB * 16 + q4;
+        for (int k = 0; k < S * NH; ++k) {            // piece k = (source j = k / NH, part h = k % NH)
+            const int j = k / NH, h = k % NH;
+            if (k + 1 < S * NH) { PB_LOAD((k + 1) & 1, (k + 1 < S * NH ? (k + 1) / NH : j), (k + 1) % NH) }
+            if (h == 0) {
 #pragma unroll
-                for (int c = 0; c < CHB; ++c)
-                    fa[(j + 1) & 1][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa + c * 16));
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             if (srcp[j]) {
 #pragma unroll
-                for (int c = 0; c < CHB; ++c) {
-                    const int kc = wave * CHB + c;
+                for (int c = 0; c < CHP; ++c) {
+                    const int kc = wave * CHB + h * CHP + c;
                     const f32x4 w = *reinterpret_cast<const f32x4*>(wl + ((j * NCHB + kc) * UW + ub) * 16 + q4);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].x, w.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].y, w.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].z, w.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 1][c].w, w.w, acc, 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k & 1][rt][c].x, w.x, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k & 1][rt][c].y, w.y, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k & 1][rt][c].z, w.z, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k & 1][rt][c].w, w.w, acc[rt], 0, 0, 0);
+                    }
                 }
             }
-            float* rp = red + (wave * S + j) * 256;
+            if (h == NH - 1) {
+                float* rp = red + (wave * S + j) * 256 * RT;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) rp[((lane >> 4) * 4 + reg) * 16 + r] = acc[reg];
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) rp[(16 * rt + (lane >> 4) * 4 + reg) * 16 + r] = acc[rt][reg];
+            }
         }
+#undef PB_LOAD
         __syncthreads();
-        // ---- epilogue of my (slot, row, unit)
-        if (eact && jact) {
-            const int o = slot * 256 + erow * 16 + ul;
-            float dh = (red[o] + red[S * 256 + o]) + (red[2 * S * 256 + o] + red[3 * S * 256 + o]);
-            if (!is_cell) {                                     // dX_l[tx]: consumed by cell(l, tx) at the next tick
-                dxl[((s + 1) & 1) * LL * 64 + el * 64 + p] = dh;
-                a.dxs[((long)el * RS + (t % RS)) * sH + hb] = dh;
-            } else {
-                if (el < LL - 1 && s != a.s_begin) ext_v = dxl[(s & 1) * LL * 64 + el * 64 + p];
-                dh += ext_v;
-                const float tc = tanhf(c_v);
-                const float d_o = dh * tc * go * (1.f - go);
-                const float dc = dh * go * (1.f - tc * tc) + dcst;
-                const float d_i = dc * gg * gi * (1.f - gi);
-                const float d_f = t > 0 ? dc * cprev_v * gf * (1.f - gf) : 0.f;
-                const float d_g = dc * gi * (1.f - gg * gg);
-                dcst = dc * gf;
-                a.dcs[((long)el * RS + (t % RS)) * sH + hb] = dcst;
-                float* dp = a.dG + el * lG + (long)t * sG + (long)eb * G + unit;
-                dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+        // ---- epilogue of my (slot, row, unit) pairs
+        if (jact) {
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int p = p0 + 64 * i;
+                const int erow = p / UW, ul = p - erow * UW;
+                if (p >= RX * UW || row0 + erow >= B) continue;
+                const int eb = row0 + erow, unit = role * UW + ul;
+                const long hb = (long)eb * H + unit;
+                const int o = slot * 256 * RT + erow * 16 + ul;
+                float dh = (red[o] + red[S * 256 * RT + o]) + (red[2 * S * 256 * RT + o] + red[3 * S * 256 * RT + o]);
+                if (!is_cell) {                                 // dX_l[tx]: consumed by cell(l, tx) at the next tick
+                    dxl[(((s + 1) & 1) * LL + el) * NP + p] = dh;
+                    a.dxs[((long)el * RS + (t % RS)) * sH + hb] = dh;
+                } else {
+                    float ext = ext_v[i];
+                    if (el < LL - 1 && s != a.s_begin) ext = dxl[((s & 1) * LL + el) * NP + p];
+                    dh += ext;
+                    const float tc = tanhf(c_v[i]);
+                    const float d_o = dh * tc * go[i] * (1.f - go[i]);
+                    const float dc = dh * go[i] * (1.f - tc * tc) + dcst[i];
+                    const float d_i = dc * gg[i] * gi[i] * (1.f - gi[i]);
+                    const float d_f = t > 0 ? dc * cprev_v[i] * gf[i] * (1.f - gf[i]) : 0.f;
+                    const float d_g = dc * gi[i] * (1.f - gg[i] * gg[i]);
+                    dcst[i] = dc * gf[i];
+                    a.dcs[((long)el * RS + (t % RS)) * sH + hb] = dcst[i];
+                    float* dp = a.dG + el * lG + (long)t * sG + (long)eb * G + unit;
+                    dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my dG stores have reached the XCD's L2
@@ -1158,29 +1190,32 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
     }
 }
 
-template <int NT, int LL>
+template <int NT, int LL, int RT>
 void launch_persist_bwd(const PersistBwdArgs& a, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_kernel<NT, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  150 * 1024);
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_kernel<NT, LL, RT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((lstm_bwd_persist_kernel<NT, LL>), dim3(256), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lstm_bwd_persist_kernel<NT, LL, RT>), dim3(256), dim3(256), lds, s, a);
 }
-inline size_t persist_bwd_lds_bytes(int H, int L) {
-    const int NT = H / 128, UW = 4 * NT, S = 2 * L - 1;
-    return sizeof(float) * ((size_t)S * (4 * H / 16) * UW * 16 + (size_t)4 * S * 256 + (size_t)2 * L * 64);
+inline size_t persist_bwd_lds_bytes(int B, int H, int L) {
+    const int NT = H / 128, UW = 4 * NT, S = 2 * L - 1, RT = persist_row_tiles(B);
+    return sizeof(float) * ((size_t)S * (4 * H / 16) * UW * 16 + (size_t)4 * S * 256 * RT + (size_t)2 * L * 16 * RT * UW);
 }
+// Opt-in (ARCVAE_PERSIST_BWD=1): measured SLOWER than the launches at every batch tried -- bs 64: tick 5.4 us alone and
+// 7-8 us beside the weight-gradient GEMMs against 5.0 / 5.4-6.3 us per launch (step 1.64 vs 1.40 ms); bs 128: 2.38 vs
+// 2.03 ms; bs 256 (two row tiles): 4.28 vs 3.30 ms.  A tick's operand is 4x the forward's (K = 4H: 96-192 KB into every
+// CU in dependent load -> MFMA rounds), its outputs are 8 units wide (half of a 16 x 16 tile at best), and blocks that
+// sit on every CU for the whole sweep feel the GEMMs' LDS / MFMA traffic in every tick.  Kept: parity-green, and the
+// base for a version with an LDS-staged operand and two sources packed into one tile.
 inline bool persist_bwd_shape_ok(int B, int T, int H, int L) {
-    // Opt-in (ARCVAE_PERSIST_BWD=1): measured SLOWER than the launches at the default shape (tick 5.4 us alone, 7-8 us
-    // beside the weight-gradient GEMMs, against 5.0 / 5.4-6.3 us per launch; step 1.64 vs 1.40 ms) -- the operand of a
-    // tick is 4x the forward's (96 KB per CU, three dependent load/MFMA rounds) and the 8 x 8 tiles use a quarter of the
-    // 16 x 16 MFMA.  Kept: parity-green, and the base for a version that packs two sources into one tile.
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0 || arcvae_env_int("ARCVAE_PERSIST_BWD", 0) == 0) return false;
     if (H % 128 != 0 || H / 128 > 3 || L < 1 || L > 2 || B < 1 || T < 1) return false;
-    if (ceil_div(B, 8) * (H / 32) > 64) return false;      // one (row, unit) pair per thread of a slot
-    return persist_bwd_lds_bytes(H, L) <= 150 * 1024;
+    const int RX = ceil_div(B, 8);
+    if (RX > 32) return false;
+    return persist_bwd_lds_bytes(B, H, L) <= 150 * 1024;
 }
 
 template <int CH>
@@ -1387,9 +1422,12 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
     a.cnt_off = chunk_no == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_no - 1);   // chunk 0: words 256..263, then 272..
     ++chunk_no;
-    const size_t lds = persist_bwd_lds_bytes(H, L);
+    const size_t lds = persist_bwd_lds_bytes(B, H, L);
     const int NT = H / 128;
-#define PB_BY_L(N_) if (L == 1) launch_persist_bwd<N_, 1>(a, lds, stream); else launch_persist_bwd<N_, 2>(a, lds, stream);
+    const int RTn = persist_row_tiles(B);
+#define PB_BY_L(N_)                                                                                          \
+    if (RTn == 2) { if (L == 1) launch_persist_bwd<N_, 1, 2>(a, lds, stream); else launch_persist_bwd<N_, 2, 2>(a, lds, stream); } \
+    else { if (L == 1) launch_persist_bwd<N_, 1, 1>(a, lds, stream); else launch_persist_bwd<N_, 2, 1>(a, lds, stream); }
     if (NT == 1) { PB_BY_L(1) } else if (NT == 2) { PB_BY_L(2) } else { PB_BY_L(3) }
 #undef PB_BY_L
     return arcvae_launch_status();
