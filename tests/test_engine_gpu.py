@@ -299,7 +299,8 @@ def test_default_model_large_batches_kernel_families_agree(B, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"ARCVAE_PERSIST": "0"}, {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "1"}])
 @pytest.mark.parametrize("H,L,B,T,C", [(128, 2, 20, 9, 1), (128, 1, 33, 7, 2), (256, 2, 64, 12, 1), (384, 1, 9, 5, 1),
-                                       (128, 2, 200, 6, 1), (256, 2, 250, 5, 1), (256, 2, 128, 6, 1)])  # > 128 rows: two row tiles per XCD
+                                       (128, 2, 200, 6, 1), (256, 2, 250, 5, 1), (256, 2, 128, 6, 1),   # > 128 rows: two row tiles per XCD
+                                       (128, 2, 3, 4, 1)])                                                # fewer rows than XCDs
 def test_persistent_sweeps_and_their_fallback(env, H, L, B, T, C, monkeypatch):
     """The persistent per-XCD sweeps (lstm_fwd_persist_kernel: default; lstm_bwd_persist_kernel: opt-in) and the
     per-step launches they replace, on shapes inside the persistent kernels' range: ragged row groups (B not a
