@@ -742,6 +742,8 @@ __device__ __forceinline__ unsigned ps_xcc_id() {
     return v & 0xf;
 }
 
+constexpr bool persist_wreg(int NT, int LL) { return (2 * LL - 1) * (2 * NT) * NT <= 32; }
+
 template <int NT, int LL, int RT>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
 __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     constexpr int CW = 16 * NT;          // gate columns per CU
@@ -751,9 +753,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     constexpr int S = 2 * LL - 1;        // weight matrices
     constexpr int TPL = 256 / LL;        // epilogue threads per layer
     constexpr int MAXP = (16 * RT * UW + TPL - 1) / TPL;
+    // Where the stationary weights live: in REGISTERS when a wave's share (its K quarter of every source:
+    // S * CHW * NT float4 per lane) is at most 32 float4 = 128 VGPRs -- the default shape needs 24 -- else in LDS.
+    // Registers take the 96 KB of LDS reads per tick off the LDS pipe (which the GEMM blocks sharing the CU also use):
+    // 1.400 -> 1.382 ms per step at the default shape (A/B on one box).
+    constexpr bool WREG = persist_wreg(NT, LL) && RT == 1;   // two row tiles: 288 VGPRs and 0.8 % slower than LDS
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;                                 // [S][NCH][CW][16]
-    float* red = lds + S * NCH * CW * 16;            // [4 waves][LL][16*RT][CW]
+    float* wl = lds;                                 // [S][NCH][CW][16]   (LDS variant only)
+    float* red = WREG ? lds : lds + S * NCH * CW * 16;   // [4 waves][LL][16*RT][CW]
     constexpr int RW = LL * 16 * RT * CW;            // floats per wave in red
     __shared__ unsigned s_role, s_xcc, s_ok;
     arcvae_set_prio(a.prio);
@@ -774,17 +781,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     }
     const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
     // stationary weights: permuted rows [role*CW, +CW) of every source
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    f32x4 wr[WREG ? S : 1][WREG ? CHW : 1][WREG ? NT : 1];
     {
         const long wsz = (long)H * G;
-        for (int i = tid; i < S * NCH * CW * 4; i += 256) {
-            const int s = i / (NCH * CW * 4), rem = i - s * (NCH * CW * 4);
-            const int kc = rem / (CW * 4), c4 = rem - kc * (CW * 4);
-            reinterpret_cast<float4*>(wl)[i] =
-                *reinterpret_cast<const float4*>(a.wt + s * wsz + ((long)kc * G + role * CW) * 16 + c4 * 4);
+        if constexpr (WREG) {
+#pragma unroll
+            for (int si = 0; si < S; ++si)
+#pragma unroll
+                for (int c = 0; c < CHW; ++c)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        wr[si][c][n] = *reinterpret_cast<const f32x4*>(
+                            a.wt + si * wsz + ((long)(wave * CHW + c) * G + role * CW + 16 * n + r) * 16 + q4);
+        } else {
+            for (int i = tid; i < S * NCH * CW * 4; i += 256) {
+                const int si = i / (NCH * CW * 4), rem = i - si * (NCH * CW * 4);
+                const int kc = rem / (CW * 4), c4 = rem - kc * (CW * 4);
+                reinterpret_cast<float4*>(wl)[i] =
+                    *reinterpret_cast<const float4*>(a.wt + si * wsz + ((long)kc * G + role * CW) * 16 + c4 * 4);
+            }
         }
     }
     __syncthreads();
-    const int r = lane & 15, q4 = (lane >> 4) * 4;
     const int row0 = xcc * RX;
     int arow[RT];                                               // tile rows beyond this XCD's rows repeat the last one
 #pragma unroll
@@ -881,7 +900,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             _Pragma("unroll") for (int c = 0; c < CHW; ++c) {                                                    \
                 const int kc = wave * CHW + c;                                                                   \
                 _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                 \
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + (((SIDX) * NCH + kc) * CW + 16 * n + r) * 16 + q4); \
+                    f32x4 w;                                                                                      \
+                    if constexpr (WREG) w = wr[WREG ? (SIDX) : 0][WREG ? c : 0][WREG ? n : 0];                     \
+                    else w = *reinterpret_cast<const f32x4*>(wl + (((SIDX) * NCH + kc) * CW + 16 * n + r) * 16 + q4); \
                     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                          \
                         acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][rt][c].x, w.x, acc[rt][n], 0, 0, 0); \
                         acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(FR[l][rt][c].y, w.y, acc[rt][n], 0, 0, 0); \
@@ -955,7 +976,10 @@ void launch_persist(const PersistArgs& a, size_t lds, hipStream_t s) {
 inline int persist_row_tiles(int B) { return ceil_div(B, 8) > 16 ? 2 : 1; }
 inline size_t persist_lds_bytes(int B, int H, int L) {
     const int NT = H / 128, CW = 16 * NT;
-    return sizeof(float) * ((size_t)(2 * L - 1) * (H / 16) * CW * 16 + (size_t)4 * L * 16 * persist_row_tiles(B) * CW);
+    const size_t red = sizeof(float) * (size_t)4 * L * 16 * persist_row_tiles(B) * CW;
+    if (persist_wreg(NT, L) && persist_row_tiles(B) == 1)   // weights in registers: only the reduction buffer is used, but the allocation stays above
+        return red > 81 * 1024 ? red : 81 * 1024;   // half the CU's LDS so that the blocks land one per CU
+    return sizeof(float) * (size_t)(2 * L - 1) * (H / 16) * CW * 16 + red;
 }
 // up to 32 rows per XCD (two MFMA row tiles): B <= 256, i.e. also the 256-row shard of BASELINE.json configs[3]
 inline bool persist_shape_ok(int B, int T, int H, int L) {
