@@ -299,8 +299,14 @@ def roofline_probe(eng, ws, torch):
     launches = Tn + 2 * (d.L - 1)
     reps = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    persistent = E.bptt_reduce_scatter_ok(ws, d)   # the BPTT sweep of this shape is ONE persistent launch per chunk
 
     def sweep():
+        if persistent:   # the whole sweep as one launch of lstm_bwd_persist_rs_kernel: `launches` ticks
+            E.call("arcvae_enc_lstm_backward_persistent_rs", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb),
+                   2 * d.H, E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.ppart), E.ptr(ws.psync), None, B, Tn,
+                   d.H, d.L, 0, launches, E.stream_ptr())
+            return
         E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * d.H,
                E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, Tn, d.H, d.L, 0, launches,
                1, None, E.stream_ptr())
@@ -313,31 +319,51 @@ def roofline_probe(eng, ws, torch):
     s = torch.cuda.current_stream()
     g.replay()
     torch.cuda.synchronize()
-    e0.record(s)
-    for _ in range(reps):
-        g.replay()
-    e1.record(s)
-    torch.cuda.synchronize()
-    us = 1e3 * e0.elapsed_time(e1) / reps / launches
+    if persistent:   # one replay = one launch: bracket every replay by its own pair of events, take the median
+        times = []
+        for _ in range(reps):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(s)
+            g.replay()
+            a1.record(s)
+            torch.cuda.synchronize()
+            times.append(a0.elapsed_time(a1))
+        us = 1e3 * sorted(times)[len(times) // 2] / launches
+    else:
+        e0.record(s)
+        for _ in range(reps):
+            g.replay()
+        e1.record(s)
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps / launches
     flops_total = 2.0 * B * 4 * d.H * d.H * (d.L * (Tn - 1) + (d.L - 1) * Tn)
     ach = flops_total / launches / (us * 1e-6) / 1e12
+    kernel = "lstm_bwd_persist_rs_kernel" if persistent else "lstm_bwd_step_kernel"
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("lstm_bwd_step_kernel", {}).get("bytes_per_launch")
+            ent = json.load(open(pmc)).get(kernel, {})
+            traffic = ent.get("bytes_per_tick", ent.get("bytes_per_launch"))
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": "lstm_bwd_step_kernel", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+    if persistent:
+        note = ("dominant kernel: the persistent BPTT sweep (lstm_bwd_persist_rs_kernel, one launch per chunk; DESIGN.md "
+                "section 6b); a 'launch' here is one TICK of it (same 2L-1 contractions as a launch of the per-step "
+                "kernel it replaced).  achieved = isolated sweep as ONE launch (HIP events on its stream) / ticks; "
+                "in_step_* = tick cadence inside the last timed step (device-side stamps, weight-gradient GEMMs beside it). "
+                "f32-input MFMA peak (exact-f32 path); a tick is bound by the per-XCD barrier and one L2 round trip of the "
+                "reduce-scatter, not by MFMA; traffic = (2*FETCH_SIZE + WRITE_SIZE) / ticks from profiles/r01_pmc_summary.json")
+    else:
+        note = ("achieved = isolated BPTT sweep (HIP events on its stream); in_step_* = start-to-start cadence of the "
+                "same launches inside the last timed step (device-side stamps, side-stream GEMMs running beside "
+                "them).  f32-input MFMA peak (exact-f32 path); the launch is bound by the dependent-chain seam "
+                "(1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6; traffic = "
+                "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_summary.json (separate --pmc passes)")
+    return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
             "us_per_launch": us, "launches_per_sweep": launches,
-            "flop_per_launch": flops_total / launches,
-            "note": "achieved = isolated BPTT sweep (HIP events on its stream); in_step_* = start-to-start cadence of the "
-                    "same launches inside the last timed step (device-side stamps, side-stream GEMMs running beside "
-                    "them).  f32-input MFMA peak (exact-f32 path); the launch is bound by the dependent-chain seam "
-                    "(1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6; traffic = "
-                    "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_summary.json (separate --pmc passes)"}
-
+            "flop_per_launch": flops_total / launches, "note": note}
 
 if __name__ == "__main__":
     main()

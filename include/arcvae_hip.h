@@ -93,6 +93,15 @@ int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, co
                                         float* dG, float* dcs, float* dxs, const float* wT, unsigned* sync_ws,
                                         unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
                                         arcvae_stream_t stream);
+/* Reduce-scatter form of the persistent BPTT sweep (H = 256, L <= 2, B <= 64): a CU keeps the gate gradients of its own
+ * 32 gate columns on chip, multiplies them with its 32 rows of the row-major Wh / Wx, and the partial sums are
+ * reduce-scattered through the XCD's L2 (part_ws: 2*(2L-1)*8*32*32*64 floats).  Otherwise as
+ * arcvae_enc_lstm_backward_persistent. */
+int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
+int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
+                                           const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
+                                           float* dxs, float* part_ws, unsigned* sync_ws, unsigned* start_signal, int B,
+                                           int T, int H, int L, int s_begin, int s_end, arcvae_stream_t stream);
 /* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,

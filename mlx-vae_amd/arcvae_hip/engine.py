@@ -117,6 +117,8 @@ class Workspace:
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
             self.dtable0 = torch.empty(V, G, **f32)
             self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)
+            if H == 256 and L <= 2 and B <= 64:   # partial sums in flight of the reduce-scatter BPTT sweep (12.6 MB)
+                self.ppart = torch.empty(2 * (2 * L - 1) * 8 * 32 * 32 * 64, **f32)
             self.dlogits = torch.empty(BV, V, **f32)
             self.ddh = torch.empty(2, BV, H, **f32)
             self.ddG = torch.empty(BV, G, **f32)
@@ -133,6 +135,15 @@ def _layer_ptrs(store: ParamStore, L: int, leaf: str, grad: bool = False, skip0:
 # --------------------------------------------------------------------------------------------
 # op-level drivers (each is a handful of C-ABI calls on the current stream)
 # --------------------------------------------------------------------------------------------
+def bptt_reduce_scatter_ok(ws, d: ModelDims) -> bool:
+    """The BPTT sweep of this shape runs as the persistent reduce-scatter kernel (lstm_bwd_persist_rs_kernel).
+    ARCVAE_PERSIST_BWD: unset / "3" = where the shape allows (H 256, L <= 2, B <= 64); "0" = per-step launches;
+    "1" = the output-split persistent kernel (slower, kept for reference)."""
+    if os.environ.get("ARCVAE_PERSIST_BWD", "3") != "3":
+        return False
+    return _lib.load().arcvae_enc_lstm_bwd_rs_ok(ws.B, ws.T, d.H, d.L) == 1
+
+
 def persistent_forward_ok(ws: Workspace, d: ModelDims) -> bool:
     """The forward sweep of this shape can run as one persistent launch (csrc/lstm.hip: lstm_fwd_persist_kernel)."""
     return _lib.load().arcvae_enc_lstm_persistent_ok(ws.B, ws.T, d.H, d.L) == 1
@@ -352,6 +363,13 @@ class EncoderBackwardPlan:
         # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
         sig = start_signal if start_signal is not None else C.c_void_p(0)
+        if bptt_reduce_scatter_ok(ws, d):
+            # latency regime, default shape: persistent BPTT sweep in its reduce-scatter form, one launch per chunk
+            # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
+            call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
+                 ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), ptr(ws.psync), sig,
+                 ws.B, ws.T, d.H, d.L, s0, s1, stream_ptr())
+            return
         if _lib.load().arcvae_enc_lstm_bwd_persistent_ok(ws.B, ws.T, d.H, d.L) == 1:
             # latency regime: one persistent launch per chunk (csrc/lstm.hip: lstm_bwd_persist_kernel)
             call("arcvae_enc_lstm_backward_persistent", ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG),

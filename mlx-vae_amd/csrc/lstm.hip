@@ -1214,6 +1214,202 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
     }
 }
 
+
+// ---- persistent BPTT sweep, reduce-scatter form (default shape) -------------------------------------------------------
+// The forward sweep is cheap per tick because a CU needs 24 KB of operand: it owns 32 GATE columns and the contraction
+// runs over the hidden units.  In the BPTT step dh = dG . Wh the contraction runs over the gate columns and the outputs
+// are hidden units, so "each CU owns some outputs" (lstm_bwd_persist_kernel) makes every CU pull all of dG: 96 KB per
+// tick.  Turn it round: a CU keeps the gate gradients of ITS 32 gate columns (the ones its own epilogue produced one
+// tick earlier: they never leave the CU) and multiplies them with its 32 ROWS of Wh -- a partial dh over ALL hidden
+// units, K = 32.  The partials are reduce-scattered through the XCD's L2: every CU writes 8 rows x 8 units for each of
+// the 32 CUs (laid out so that a consumer's 32 pieces are one contiguous 8 KB), one barrier, every CU sums the 32
+// pieces of its own units.  Per tick and source a CU writes 8 KB and reads 8 KB; the MFMA work is 32 instructions
+// per wave and source.  Weights: the CU's 32 rows of the ORIGINAL row-major Wh / Wx (no transposed copy), in LDS.
+// Shape: H = 256 (32 CUs x 8 units), L <= 2, at most 8 rows per XCD.  Chunks, signals, rings: as lstm_bwd_persist_kernel.
+struct PersistRsArgs {
+    PersistBwdArgs b;
+    const float* W[3];        // row-major [4H,H]: cell(l=1) Wh_1, cell(l=0) Wh_0, xproj(0) Wx_1   (slot order; L = 1: W[0] = Wh_0)
+    float* part;              // [2 parity][S][8 XCDs][32 consumers][32 producers][64]  partial sums in flight
+};
+
+template <int LL>
+__global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
+    const PersistBwdArgs& a = ar.b;
+    constexpr int UW = 8, S = 2 * LL - 1, WS = 36;   // WS: padded row stride of the weight image (bank-conflict-free b128 reads)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wloc = lds;                                // [S][256 units][WS]: W[my gate col k][unit], k-contiguous
+    float* dgl = wloc + S * 256 * WS;                 // [LL][16 rows][32 gate cols of mine]  (rows >= 8 stay zero)
+    float* dxl = dgl + LL * 16 * 32;                  // [2][64]
+    __shared__ unsigned s_role, s_xcc, s_ok;
+    arcvae_set_prio(a.prio);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, T = a.T, H = a.H, G = 4 * a.H, RX = a.RX, RS = a.RS;
+    if (tid == 0) {
+        s_xcc = ps_xcc_id();
+        s_role = atomicAdd(a.sync + PS_CNT + a.cnt_off + (s_xcc & 7), 1u);
+        s_ok = 1;
+        if (blockIdx.x == 0 && a.start_signal)
+            __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned xcc = s_xcc, role = s_role;
+    if (xcc >= 8 || role >= 32) {
+        if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
+        return;
+    }
+    const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
+    // my 32 rows of every weight matrix, transposed into [unit][k]: k = gate * 8 + ul  <->  row gate*H + 8*role + ul
+    // (thread tid takes unit column j = tid of every row; the 32 loads of a source are all in flight before the first
+    // LDS store -- one load -> store round trip per element made a chunk launch cost 55 us)
+#pragma unroll
+    for (int si = 0; si < S; ++si) {
+        float wv[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) wv[k] = ar.W[si][(long)((k >> 3) * H + role * UW + (k & 7)) * H + tid];
+#pragma unroll
+        for (int k = 0; k < 32; k += 4)
+            *reinterpret_cast<f32x4*>(wloc + (si * 256 + tid) * WS + k) = f32x4{wv[k], wv[k + 1], wv[k + 2], wv[k + 3]};
+    }
+    for (int i = tid; i < LL * 16 * 32; i += 256) dgl[i] = 0.f;
+    __syncthreads();
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    const int row0 = xcc * RX;
+    const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
+    const int slot = tid >> 6, p = tid & 63;          // slots: cell(l) -> LL-1-l, xproj(0) -> LL (as lstm_bwd_persist_kernel)
+    const bool is_cell = slot < LL;
+    const int el = is_cell ? (LL - 1 - slot) : (slot - LL);
+    const int erow = p >> 3, ul = p & 7;
+    const bool eact = slot < S && erow < RX && row0 + erow < B;
+    const int eb = min(row0 + erow, B - 1), unit = role * UW + ul;
+    const long hb = (long)eb * H + unit;
+    float dcst = 0.f;
+    unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
+    const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
+    const long part_src = (long)8 * 32 * 32 * 64;     // floats per (parity, source)
+
+    for (int s = a.s_begin; s < a.s_end; ++s) {
+        const int skew = 2 * (LL - 1 - el);
+        const int t = is_cell ? T - 1 - (s - skew) : T - 1 - (s + 1 - skew);
+        const bool jact = slot < S && t >= 0 && t < T;
+        // forward values of my epilogue (static) -- requested first
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c_v = 0.f, cprev_v = 0.f, ext_v = 0.f;
+        if (eact && is_cell && jact) {
+            const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb * G + unit;
+            gi = gp[0]; gf = gp[H]; gg = gp[2 * H]; go = gp[3 * H];
+            c_v = a.cseq[el * lH + (long)t * sH + hb];
+            if (t > 0) cprev_v = a.cseq[el * lH + (long)(t - 1) * sH + hb];
+            if (el == LL - 1 && t == T - 1) ext_v = a.dh_top[(long)eb * a.ld_dh_top + unit];
+            if (s == a.s_begin) {
+                dcst = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb] : 0.f;
+                if (el < LL - 1) ext_v = a.dxs[((long)el * RS + (t % RS)) * sH + hb];
+            }
+        }
+        // first tick of a chunk: my gate columns of the gradients the previous chunk left in memory
+        if (s == a.s_begin) {
+            for (int i = tid; i < LL * 8 * 32; i += 256) {
+                const int l = i / 256, rem = i - l * 256, rw = rem >> 5, k = rem & 31;
+                const int tl_ = T - 1 - (s - 2 * (LL - 1 - l));          // cell(l, tl_) of this tick reads dG^l_{tl_ + 1}
+                float v = 0.f;
+                if (tl_ + 1 >= 0 && tl_ + 1 < T && rw < RX && row0 + rw < B)
+                    v = a.dG[l * lG + (long)(tl_ + 1) * sG + (long)(row0 + rw) * G + (k >> 3) * H + role * UW + (k & 7)];
+                dgl[(l * 16 + rw) * 32 + k] = v;
+            }
+            __syncthreads();
+        }
+        if (tr) a.trace[2 * s] = wall_clock64();
+        // ---- partial products of the S slots from my local gate gradients; wave w covers units [64w, 64w + 64)
+        float* pbase = ar.part + (long)(s & 1) * S * part_src + (long)xcc * 32 * 32 * 64;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const bool cellj = j < LL;
+            const int lj = cellj ? (LL - 1 - j) : (j - LL);
+            const int skj = 2 * (LL - 1 - lj);
+            const int tj = cellj ? T - 1 - (s - skj) : T - 1 - (s + 1 - skj);
+            const bool actj = tj >= 0 && tj < T && (!cellj || tj < T - 1);
+            const int ls = cellj ? lj : lj + 1;                         // layer whose local gradients feed this slot
+            f32x4 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (actj) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(dgl + (ls * 16 + r) * 32 + 16 * c + q4);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wloc + (j * 256 + 64 * wave + 16 * n + r) * WS + 16 * c + q4);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w.x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w.y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w.z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w.w, acc[n], 0, 0, 0);
+                    }
+                }
+            }
+            // scatter: rows 0..7 (lanes with lane>>4 < 2), unit ju = 64w + 16n + r -> consumer ju>>3, piece [row][ju&7]
+            if ((lane >> 4) < 2) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int ju = 64 * wave + 16 * n + r;
+                    float* dst = pbase + j * part_src + ((long)(ju >> 3) * 32 + role) * 64 + (ju & 7);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) dst[((lane >> 4) * 4 + reg) * 8] = acc[n][reg];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my partials have reached the XCD's L2
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // ---- every CU of my XCD has published its partials of tick s
+        if (wave == 0) {
+            unsigned spins = 0;
+            while (true) {
+                const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : (unsigned)(s + 1);
+                if (__all((int)(v - (unsigned)(s + 1)) >= 0)) break;
+                if (++spins > 4000000u || __hip_atomic_load(a.sync + PS_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) { atomicAdd(a.sync + PS_ERR, 1u); s_ok = 0; }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        // ---- gather: the 32 pieces of my (slot, row, unit)
+        float dh = 0.f;
+        if (eact && jact) {
+            const float* src = pbase + slot * part_src + ((long)role * 32) * 64 + p;
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = __builtin_nontemporal_load(src + i * 64);
+#pragma unroll
+            for (int i = 0; i < 32; i += 4) dh += (v[i] + v[i + 1]) + (v[i + 2] + v[i + 3]);
+        }
+        if (eact && jact) {
+            if (!is_cell) {
+                dxl[((s + 1) & 1) * 64 + p] = dh;
+                a.dxs[((long)el * RS + (t % RS)) * sH + hb] = dh;
+            } else {
+                if (el < LL - 1 && s != a.s_begin) ext_v = dxl[(s & 1) * 64 + p];
+                dh += ext_v;
+                const float tc = tanhf(c_v);
+                const float d_o = dh * tc * go * (1.f - go);
+                const float dc = dh * go * (1.f - tc * tc) + dcst;
+                const float d_i = dc * gg * gi * (1.f - gi);
+                const float d_f = t > 0 ? dc * cprev_v * gf * (1.f - gf) : 0.f;
+                const float d_g = dc * gi * (1.f - gg * gg);
+                dcst = dc * gf;
+                a.dcs[((long)el * RS + (t % RS)) * sH + hb] = dcst;
+                float* dp = a.dG + el * lG + (long)t * sG + (long)eb * G + unit;
+                dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+                float* dl = dgl + (el * 16 + erow) * 32 + ul;        // my gate columns stay on the CU for the next tick
+                dl[0] = d_i; dl[8] = d_f; dl[16] = d_g; dl[24] = d_o;
+            }
+        }
+        __syncthreads();
+        if (tr) a.trace[2 * s + 1] = wall_clock64();
+    }
+}
+
 template <int NT, int LL, int RT>
 void launch_persist_bwd(const PersistBwdArgs& a, size_t lds, hipStream_t s) {
     static bool attr_set = false;
@@ -1454,6 +1650,56 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
     else { if (L == 1) launch_persist_bwd<N_, 1, 1>(a, lds, stream); else launch_persist_bwd<N_, 2, 1>(a, lds, stream); }
     if (NT == 1) { PB_BY_L(1) } else if (NT == 2) { PB_BY_L(2) } else { PB_BY_L(3) }
 #undef PB_BY_L
+    return arcvae_launch_status();
+}
+
+
+// 1 if arcvae_enc_lstm_backward_persistent_rs supports the shape (and ARCVAE_PERSIST != 0).
+extern "C" int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L) {
+    return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && H == 256 && L >= 1 && L <= 2 && B >= 1 && B <= 64 && T >= 1) ? 1 : 0;
+}
+
+// Reduce-scatter form of the persistent BPTT sweep (lstm_bwd_persist_rs_kernel): H = 256, L <= 2, B <= 64.
+//   Wx / Wh: HOST arrays of the row-major weights (as arcvae_enc_lstm_backward);  part_ws: 2 * (2L-1) * 8 * 32 * 32 * 64
+//   floats of scratch for the partial sums in flight.  Everything else as arcvae_enc_lstm_backward_persistent.
+extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
+                                                      const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
+                                                      float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
+                                                      unsigned* start_signal, int B, int T, int H, int L, int s_begin,
+                                                      int s_end, hipStream_t stream) {
+    if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !part_ws || !sync_ws) return ARCVAE_ERR_ARG;
+    if (H != 256 || L < 1 || L > 2 || B < 1 || B > 64 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
+    if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
+    const int S = T + 2 * (L - 1);
+    if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
+    static int chunk_no = 0;
+    if (s_begin == 0) {
+        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+        if (rc != ARCVAE_OK) return rc;
+        chunk_no = 0;
+    }
+    if (chunk_no >= 8) return ARCVAE_ERR_ARG;
+    PersistRsArgs ar;
+    PersistBwdArgs& a = ar.b;
+    a.wT = nullptr; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
+    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace_slot(g_trace_cap / 2);
+    a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
+    a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
+    a.cnt_off = chunk_no == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_no - 1);
+    ++chunk_no;
+    if (L == 2) { ar.W[0] = Wh[1]; ar.W[1] = Wh[0]; ar.W[2] = Wx[1]; }
+    else { ar.W[0] = Wh[0]; ar.W[1] = Wh[0]; ar.W[2] = Wh[0]; }
+    for (int i = 0; i < 2 * L - 1; ++i) if (!ar.W[i]) return ARCVAE_ERR_ARG;
+    ar.part = part_ws;
+    const size_t lds = sizeof(float) * ((size_t)(2 * L - 1) * 256 * 36 + (size_t)L * 16 * 32 + 128);
+    static bool attr1 = false, attr2 = false;
+    if (L == 1) {
+        if (!attr1) { (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_rs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr1 = true; }
+        hipLaunchKernelGGL(lstm_bwd_persist_rs_kernel<1>, dim3(256), dim3(256), lds > 81 * 1024 ? lds : 81 * 1024, stream, ar);
+    } else {
+        if (!attr2) { (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_rs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr2 = true; }
+        hipLaunchKernelGGL(lstm_bwd_persist_rs_kernel<2>, dim3(256), dim3(256), lds > 81 * 1024 ? lds : 81 * 1024, stream, ar);
+    }
     return arcvae_launch_status();
 }
 

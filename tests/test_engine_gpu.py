@@ -297,13 +297,15 @@ def test_default_model_large_batches_kernel_families_agree(B, monkeypatch):
     assert rel_err(a[1], b[1]) < 1e-4
 
 
-@pytest.mark.parametrize("env", [{"ARCVAE_PERSIST": "0"}, {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "1"}])
+@pytest.mark.parametrize("env", [{"ARCVAE_PERSIST": "0"}, {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "1"},
+                                 {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "0"}, {"ARCVAE_PERSIST": "1"}])
 @pytest.mark.parametrize("H,L,B,T,C", [(128, 2, 20, 9, 1), (128, 1, 33, 7, 2), (256, 2, 64, 12, 1), (384, 1, 9, 5, 1),
                                        (128, 2, 200, 6, 1), (256, 2, 250, 5, 1), (256, 2, 128, 6, 1),   # > 128 rows: two row tiles per XCD
-                                       (128, 2, 3, 4, 1)])                                                # fewer rows than XCDs
+                                       (128, 2, 3, 4, 1),                                                 # fewer rows than XCDs
+                                       (256, 2, 37, 9, 2), (256, 1, 64, 5, 1)])                           # reduce-scatter BPTT: ragged rows, one layer
 def test_persistent_sweeps_and_their_fallback(env, H, L, B, T, C, monkeypatch):
-    """The persistent per-XCD sweeps (lstm_fwd_persist_kernel: default; lstm_bwd_persist_kernel: opt-in) and the
-    per-step launches they replace, on shapes inside the persistent kernels' range: ragged row groups (B not a
+    """The persistent per-XCD sweeps (lstm_fwd_persist_kernel; BPTT: lstm_bwd_persist_rs_kernel by default at H = 256,
+    lstm_bwd_persist_kernel with ARCVAE_PERSIST_BWD=1) and the per-step launches they replace, on shapes inside the persistent kernels' range: ragged row groups (B not a
     multiple of 8), one and two layers, every NT = H / 128, BPTT in chunks.  Same bar: 1e-4 against the fp64 oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
