@@ -163,24 +163,37 @@ def main():
     wl_ref = "BASELINE.json configs[1]" if (args.config == "default" and B == 64) else (
         "BASELINE.json configs[2]" if (args.config == "big" and B == 512) else "non-headline batch size")
     dims = E.ModelDims(V=V, E=EMB, H=H, Z=Z, C=C, L=L)
-    gen = torch.Generator().manual_seed(1234)  # identical initial weights on every rank
     enc = ParamStore(encoder_shapes(V, EMB, H, Z, C, L), dev)
     dec = ParamStore(decoder_shapes(V, EMB, H, Z, C, L), dev)
-    enc.init_mlx_like(H, gen)
-    dec.init_mlx_like(H, gen)
-    enc.p("fc_logvar.bias").fill_(0.35)
-    eng = E.StepEngine(enc, dec, dims)
     mode = args.mode
     if mode == "auto":
         mode = "eager" if args.no_graph else "segments"
-    eng.mode = mode
-    ws = eng.workspace(B, T, train=True)
-    eng.set_hyper(ws, **HYPER)
     # device-side launch stamps (two 8-byte stores per step launch): the in-step cadence of the dominant kernel is
     # reported next to its isolated timing (set before the first step: the pointers are baked into the captured graphs)
     trace_cap = 2 * (T + 2 * L + 4)
     trace_buf = torch.zeros(2 * trace_cap, dtype=torch.int64, device=dev)
     _lib.call("arcvae_set_step_trace", _lib.ptr(trace_buf), trace_cap)
+
+    def make_engine():
+        """(Re)initialise the weights and build engine, workspace and DP driver under the current ARCVAE_* knobs."""
+        gen = torch.Generator().manual_seed(1234)  # identical initial weights on every rank
+        enc.init_mlx_like(H, gen)
+        dec.init_mlx_like(H, gen)
+        enc.p("fc_logvar.bias").fill_(0.35)
+        for st in (enc, dec):
+            st.grad.zero_()
+            st.adam_m.zero_()
+            st.adam_v.zero_()
+        eng_ = E.StepEngine(enc, dec, dims)
+        eng_.mode = mode
+        ws_ = eng_.workspace(B, T, train=True)
+        eng_.set_hyper(ws_, **HYPER)
+        dp_ = None
+        if use_dp:
+            dp_ = DataParallelStep(EngineOps(eng_, ws_, LR, B * world, use_graph=(mode != "eager")))
+        return eng_, ws_, dp_
+
+    eng, ws, dp = make_engine()
 
     # device-resident synthetic batches (per-rank shard) and per-step coins (same on every rank, Q5)
     rs = np.random.RandomState(67 + rank)
@@ -194,10 +207,6 @@ def main():
     crs = np.random.RandomState(4242)
     total = args.warmup + args.steps
     coins = torch.tensor((crs.rand(total, T) < TF_RATIO).astype(np.uint8), device=dev)
-
-    dp = None
-    if use_dp:
-        dp = DataParallelStep(EngineOps(eng, ws, LR, B * world, use_graph=(mode != "eager")))
 
     def one_step(i):
         k = i % nbuf
@@ -216,9 +225,39 @@ def main():
         emit(json.dumps({"roofline": roofline_probe(eng, ws, torch)}))
         return
     log(f"rank {rank}/{world}: warm-up ({args.warmup} steps, mode={mode})")
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
+    fallback = None
+    for attempt in range(3):
+        for i in range(args.warmup):
+            one_step(i)
+        torch.cuda.synchronize()
+        # Health check before anything is timed: a device-side gate or a persistent sweep that gave up waiting (a
+        # device whose queues / CUs are not laid out as probed) must not produce a number.  All ranks agree, then
+        # everybody drops one level: gates -> event waits, persistent sweeps -> per-step launches.
+        bad = 0
+        try:
+            eng.check_gates()
+        except _lib.ArcvaeHipError as e:
+            log(f"rank {rank}: {e}")
+            bad = 1
+        if attempt < int(os.environ.get("ARCVAE_BENCH_TEST_FALLBACK", "0")):
+            bad = 1                                  # rehearsal of the fallback path (tests / tools only)
+        if world > 1:
+            bt = torch.tensor([bad], device=dev, dtype=torch.int32)
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+            bad = int(bt.item())
+        if not bad:
+            break
+        if attempt == 0:
+            os.environ["ARCVAE_GATES"] = "0"
+            fallback = "event waits instead of device-side gates"
+        elif attempt == 1:
+            os.environ["ARCVAE_PERSIST"] = "0"
+            fallback = "event waits, per-step launches instead of persistent sweeps"
+        else:
+            raise SystemExit("bench.py: the step does not run cleanly on this device even without gates and "
+                             "persistent sweeps")
+        log(f"rank {rank}: falling back to {fallback}")
+        eng, ws, dp = make_engine()
     log("timing")
     if world > 1:
         dist.barrier()
@@ -252,7 +291,7 @@ def main():
             "config": {"workload": f"{wl_name}, bs {B}/GPU, T 128, tf 0.9, "
                                    f"beta 0 (epoch-0 schedule), fwd+bwd+Adam ({wl_ref})",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "launch_mode": mode},
+                       "launch_mode": mode, "fallback": fallback},
             "elbo": {"total": float(scal[0]), "recon": float(scal[1]), "kl": float(scal[2]),
                      "mutual_info": float(scal[7])},
             "step_tflops_algorithmic": seqs * f_seq / 1e12,

@@ -1232,13 +1232,13 @@ struct PersistRsArgs {
     float* part;              // [2 parity][S][8 XCDs][32 consumers][32 producers][64]  partial sums in flight
 };
 
-template <int LL>
+template <int LL, bool WR>   // WR: the weight slices live in registers (a wave's share is 24 float4 per lane), else in LDS
 __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
     const PersistBwdArgs& a = ar.b;
     constexpr int UW = 8, S = 2 * LL - 1, WS = 36;   // WS: padded row stride of the weight image (bank-conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wloc = lds;                                // [S][256 units][WS]: W[my gate col k][unit], k-contiguous
-    float* dgl = wloc + S * 256 * WS;                 // [LL][16 rows][32 gate cols of mine]  (rows >= 8 stay zero)
+    float* wloc = lds;                                // [S][256 units][WS]: W[my gate col k][unit], k-contiguous (LDS variant)
+    float* dgl = wloc + (WR ? 0 : S * 256 * WS);      // [LL][16 rows][32 gate cols of mine]  (rows >= 8 stay zero)
     float* dxl = dgl + LL * 16 * 32;                  // [2][64]
     __shared__ unsigned s_role, s_xcc, s_ok;
     arcvae_set_prio(a.prio);
@@ -1258,21 +1258,37 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         return;
     }
     const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
-    // my 32 rows of every weight matrix, transposed into [unit][k]: k = gate * 8 + ul  <->  row gate*H + 8*role + ul
-    // (thread tid takes unit column j = tid of every row; the 32 loads of a source are all in flight before the first
-    // LDS store -- one load -> store round trip per element made a chunk launch cost 55 us)
+    // my 32 rows of every weight matrix as the MFMA's B operand: element (k, unit) = W[gate*H + 8*role + ul][unit] with
+    // k = gate * 8 + ul.  Register variant: lane (r, q4) of wave w keeps k = 16c + q4 + e, unit = 64w + 16n + r.
+    // LDS variant: transposed image [unit][k]; thread tid takes unit column tid of every row, the 32 loads of a source
+    // all in flight before the first LDS store (one load -> store round trip per element made a chunk launch cost 55 us).
+    const int r = lane & 15, q4 = (lane >> 4) * 4;
+    f32x4 wr[WR ? S : 1][WR ? 4 : 1][WR ? 2 : 1];
+    if constexpr (WR) {
 #pragma unroll
-    for (int si = 0; si < S; ++si) {
-        float wv[32];
+        for (int si = 0; si < S; ++si)
 #pragma unroll
-        for (int k = 0; k < 32; ++k) wv[k] = ar.W[si][(long)((k >> 3) * H + role * UW + (k & 7)) * H + tid];
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int k = 0; k < 32; k += 4)
-            *reinterpret_cast<f32x4*>(wloc + (si * 256 + tid) * WS + k) = f32x4{wv[k], wv[k + 1], wv[k + 2], wv[k + 3]};
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * c + q4 + e;
+                        wr[si][n][c][e] = ar.W[si][(long)((k >> 3) * H + role * UW + (k & 7)) * H + 64 * wave + 16 * n + r];
+                    }
+    } else {
+#pragma unroll
+        for (int si = 0; si < S; ++si) {
+            float wv[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) wv[k] = ar.W[si][(long)((k >> 3) * H + role * UW + (k & 7)) * H + tid];
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                *reinterpret_cast<f32x4*>(wloc + (si * 256 + tid) * WS + k) = f32x4{wv[k], wv[k + 1], wv[k + 2], wv[k + 3]};
+        }
     }
     for (int i = tid; i < LL * 16 * 32; i += 256) dgl[i] = 0.f;
     __syncthreads();
-    const int r = lane & 15, q4 = (lane >> 4) * 4;
     const int row0 = xcc * RX;
     const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
     const int slot = tid >> 6, p = tid & 63;          // slots: cell(l) -> LL-1-l, xproj(0) -> LL (as lstm_bwd_persist_kernel)
@@ -1336,7 +1352,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                     const f32x4 av = *reinterpret_cast<const f32x4*>(dgl + (ls * 16 + r) * 32 + 16 * c + q4);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(wloc + (j * 256 + 64 * wave + 16 * n + r) * WS + 16 * c + q4);
+                        f32x4 w;
+                        if constexpr (WR) w = wr[WR ? j : 0][WR ? n : 0][WR ? c : 0];
+                        else w = *reinterpret_cast<const f32x4*>(wloc + (j * 256 + 64 * wave + 16 * n + r) * WS + 16 * c + q4);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w.x, acc[n], 0, 0, 0);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w.y, acc[n], 0, 0, 0);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w.z, acc[n], 0, 0, 0);
@@ -1691,15 +1709,16 @@ extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, co
     else { ar.W[0] = Wh[0]; ar.W[1] = Wh[0]; ar.W[2] = Wh[0]; }
     for (int i = 0; i < 2 * L - 1; ++i) if (!ar.W[i]) return ARCVAE_ERR_ARG;
     ar.part = part_ws;
-    const size_t lds = sizeof(float) * ((size_t)(2 * L - 1) * 256 * 36 + (size_t)L * 16 * 32 + 128);
-    static bool attr1 = false, attr2 = false;
-    if (L == 1) {
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_rs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr1 = true; }
-        hipLaunchKernelGGL(lstm_bwd_persist_rs_kernel<1>, dim3(256), dim3(256), lds > 81 * 1024 ? lds : 81 * 1024, stream, ar);
-    } else {
-        if (!attr2) { (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_rs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr2 = true; }
-        hipLaunchKernelGGL(lstm_bwd_persist_rs_kernel<2>, dim3(256), dim3(256), lds > 81 * 1024 ? lds : 81 * 1024, stream, ar);
-    }
+    // ARCVAE_RS_WREG=0: weight slices in LDS instead of registers.  Either way at least 81 KB of LDS: one block per CU.
+    const bool wreg = arcvae_env_int("ARCVAE_RS_WREG", 1) != 0;
+    size_t lds = sizeof(float) * ((wreg ? 0 : (size_t)(2 * L - 1) * 256 * 36) + (size_t)L * 16 * 32 + 128);
+    if (lds < 81 * 1024) lds = 81 * 1024;
+    auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, stream, ar);
+    };
+    if (L == 1) { if (wreg) launch(lstm_bwd_persist_rs_kernel<1, true>); else launch(lstm_bwd_persist_rs_kernel<1, false>); }
+    else        { if (wreg) launch(lstm_bwd_persist_rs_kernel<2, true>); else launch(lstm_bwd_persist_rs_kernel<2, false>); }
     return arcvae_launch_status();
 }
 
