@@ -69,6 +69,28 @@ __device__ __forceinline__ void arcvae_set_prio(int p) {
 // Accurate (non fast-math) transcendental forms: parity mode needs ~1-2 ulp expf/tanhf.
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Activations of the PERSISTENT sweeps, where one wave per layer evaluates them on the dependent chain of every tick:
+// the libm forms cost ~180 VALU instructions per cell (3 sigmoids of ~30, 2 tanh of ~43), ~0.3 us of a 3.6 us tick.
+// Hardware forms instead: v_exp_f32 / v_rcp_f32 are 1-ulp instructions; sigmoid = rcp(1 + exp2(-x log2 e)) stays within
+// ~4e-7 relative; tanh = (1 - e) / (1 + e), e = exp(-2|x|), and an odd polynomial below |x| = 0.25 where that quotient
+// would lose relative accuracy to cancellation (truncation 8e-9): ~3e-7 relative everywhere.  Three orders below the
+// 1e-4 parity bar.  -DARCVAE_ACCURATE_ACT restores the libm forms.
+#ifdef ARCVAE_ACCURATE_ACT
+__device__ __forceinline__ float chain_sigmoid(float x) { return sigmoidf_acc(x); }
+__device__ __forceinline__ float chain_tanh(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float chain_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float chain_tanh(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * ax);
+    const float big = copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+    const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+    return ax < 0.25f ? small : big;
+}
+#endif
+
 // Wave-level reductions over 64 lanes.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -943,14 +943,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                     const int o = el * 16 * RT * CW + cb + 4 * g;
                     v[g] = (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]);
                 }
-                const float gi = sigmoidf_acc(v[0] + pv[i][0]);
-                const float gf = sigmoidf_acc(v[1] + pv[i][1]);
-                const float gg = tanhf(v[2] + pv[i][2]);
-                const float go = sigmoidf_acc(v[3] + pv[i][3]);
+                const float gi = chain_sigmoid(v[0] + pv[i][0]);
+                const float gf = chain_sigmoid(v[1] + pv[i][1]);
+                const float gg = chain_tanh(v[2] + pv[i][2]);
+                const float go = chain_sigmoid(v[3] + pv[i][3]);
                 const float c = te > 0 ? gf * cst[i] + gi * gg : gi * gg;   // MLX: cell=None at t == 0 -> c = i*g
                 cst[i] = c;
                 const long hb = (long)b * H + unit;
-                a.hseq[el * lH + (long)te * sH + hb] = go * tanhf(c);
+                a.hseq[el * lH + (long)te * sH + hb] = go * chain_tanh(c);
                 float* gp = a.gseq + el * lG + (long)te * sG + (long)b * G + unit;
                 gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
                 a.cseq[el * lH + (long)te * sH + hb] = c;
@@ -1232,8 +1232,15 @@ struct PersistRsArgs {
     float* part;              // [2 parity][S][8 XCDs][32 consumers][32 producers][64]  partial sums in flight
 };
 
-template <int LL, bool WR>   // WR: the weight slices live in registers (a wave's share is 24 float4 per lane), else in LDS
+// MF = 1 (registers only): the contraction on v_mfma_f32_4x4x1 (16 blocks of 4x4, K = 1) instead of 16x16x4.  An XCD owns
+// at most 8 batch rows, so a 16-row tile is half empty and the 96 16x16x4 instructions per wave and tick (32 cycles
+// each: 1.28 us of a 3.4 us tick) do twice the useful work.  With blocks = 2 row groups x 8 unit groups one 4x4x1
+// instruction (8 cycles) covers 8 rows x 32 units for one k without a padded row: 192 instructions, 0.64 us.  Weights
+// are the A operand (lane (rg, ug, i): W[k][32ch + 4ug + i], 192 VGPRs), the local gate gradients the B operand
+// (lane (rg, ug, j): dG[4rg + j][k], broadcast reads from LDS); a lane ends up with 4 consecutive units of one row.
+template <int LL, bool WR, int MF>   // WR: the weight slices live in registers, else in LDS
 __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
+    static_assert(MF == 0 || WR, "the 4x4x1 form keeps its weights in registers");
     const PersistBwdArgs& a = ar.b;
     constexpr int UW = 8, S = 2 * LL - 1, WS = 36;   // WS: padded row stride of the weight image (bank-conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1263,8 +1270,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
     // LDS variant: transposed image [unit][k]; thread tid takes unit column tid of every row, the 32 loads of a source
     // all in flight before the first LDS store (one load -> store round trip per element made a chunk launch cost 55 us).
     const int r = lane & 15, q4 = (lane >> 4) * 4;
-    f32x4 wr[WR ? S : 1][WR ? 4 : 1][WR ? 2 : 1];
-    if constexpr (WR) {
+    f32x4 wr[(WR && !MF) ? S : 1][(WR && !MF) ? 4 : 1][(WR && !MF) ? 2 : 1];
+    float wq[MF ? S : 1][MF ? 2 : 1][MF ? 32 : 1];
+    const int rg = lane >> 5, ug = (lane >> 2) & 7, ij = lane & 3;     // 4x4x1 blocks: (row group, unit group), index in block
+    if constexpr (MF == 1) {
+#pragma unroll
+        for (int si = 0; si < S; ++si)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int k = 0; k < 32; ++k)
+                    wq[si][ch][k] = ar.W[si][(long)((k >> 3) * H + role * UW + (k & 7)) * H + 64 * wave + 32 * ch + 4 * ug + ij];
+    } else if constexpr (WR) {
 #pragma unroll
         for (int si = 0; si < S; ++si)
 #pragma unroll
@@ -1343,6 +1360,37 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             const int tj = cellj ? T - 1 - (s - skj) : T - 1 - (s + 1 - skj);
             const bool actj = tj >= 0 && tj < T && (!cellj || tj < T - 1);
             const int ls = cellj ? lj : lj + 1;                         // layer whose local gradients feed this slot
+            if constexpr (MF == 1) {
+                // lane (rg, ug, ij): row 4rg + ij, units ju0 .. ju0+3 -> consumer ju0>>3, piece [row][ju0&7 ..]
+                float* pdst = pbase + j * part_src + ((long)((64 * wave + 4 * ug) >> 3) * 32 + role) * 64 + (4 * rg + ij) * 8 + ((4 * ug) & 7);
+                if (actj) {
+                    f32x4 bq[8];
+#pragma unroll
+                    for (int k4 = 0; k4 < 8; ++k4)
+                        bq[k4] = *reinterpret_cast<const f32x4*>(dgl + (ls * 16 + 4 * rg + ij) * 32 + 4 * k4);
+                    f32x4 acc[2][2];      // two independent chains per unit chunk (first link: C = 0)
+#pragma unroll
+                    for (int k4 = 0; k4 < 8; ++k4)
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch) {
+                            const int sj = MF ? j : 0, sc = MF ? ch : 0, sk = MF ? 4 * k4 : 0;
+                            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                            acc[ch][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + 0], bq[k4].x, k4 ? acc[ch][0] : z, 0, 0, 0);
+                            acc[ch][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF ? 1 : 0)], bq[k4].y, k4 ? acc[ch][1] : z, 0, 0, 0);
+                            acc[ch][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF ? 2 : 0)], bq[k4].z, acc[ch][0], 0, 0, 0);
+                            acc[ch][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF ? 3 : 0)], bq[k4].w, acc[ch][1], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)   // unit chunk ch: units + 32 -> consumer + 4
+                        *reinterpret_cast<f32x4*>(pdst + (long)ch * 4 * 32 * 64) =
+                            f32x4{acc[ch][0].x + acc[ch][1].x, acc[ch][0].y + acc[ch][1].y,
+                                  acc[ch][0].z + acc[ch][1].z, acc[ch][0].w + acc[ch][1].w};
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                        *reinterpret_cast<f32x4*>(pdst + (long)ch * 4 * 32 * 64) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
             f32x4 acc[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1355,23 +1403,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                         f32x4 w;
                         if constexpr (WR) w = wr[WR ? j : 0][WR ? n : 0][WR ? c : 0];
                         else w = *reinterpret_cast<const f32x4*>(wloc + (j * 256 + 64 * wave + 16 * n + r) * WS + 16 * c + q4);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w.x, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w.y, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w.z, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w.w, acc[n], 0, 0, 0);
+                        // weights as the A operand: the product comes out transposed, lane (row r, units 4*(lane>>4)+reg)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, av.x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, av.y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, av.z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, av.w, acc[n], 0, 0, 0);
                     }
                 }
             }
-            // scatter: rows 0..7 (lanes with lane>>4 < 2), unit ju = 64w + 16n + r -> consumer ju>>3, piece [row][ju&7]
-            if ((lane >> 4) < 2) {
+            // scatter: rows 0..7 (lanes with r < 8); a lane holds 4 consecutive units ju0.. of its row -> consumer
+            // ju0>>3, piece [row][ju0&7 ..]: one 16-byte store per tile (4 per slot instead of 16 dword stores)
+            if (r < 8) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const int ju = 64 * wave + 16 * n + r;
-                    float* dst = pbase + j * part_src + ((long)(ju >> 3) * 32 + role) * 64 + (ju & 7);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) dst[((lane >> 4) * 4 + reg) * 8] = acc[n][reg];
+                    const int ju0 = 64 * wave + 16 * n + q4;
+                    *reinterpret_cast<f32x4*>(pbase + j * part_src + ((long)(ju0 >> 3) * 32 + role) * 64 + r * 8 + (ju0 & 7)) = acc[n];
                 }
             }
+                    }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my partials have reached the XCD's L2
         __syncthreads();
@@ -1409,7 +1458,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             } else {
                 if (el < LL - 1 && s != a.s_begin) ext_v = dxl[(s & 1) * 64 + p];
                 dh += ext_v;
-                const float tc = tanhf(c_v);
+                const float tc = chain_tanh(c_v);
                 const float d_o = dh * tc * go * (1.f - go);
                 const float dc = dh * go * (1.f - tc * tc) + dcst;
                 const float d_i = dc * gg * gi * (1.f - gi);
@@ -1717,8 +1766,17 @@ extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, co
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, stream, ar);
     };
-    if (L == 1) { if (wreg) launch(lstm_bwd_persist_rs_kernel<1, true>); else launch(lstm_bwd_persist_rs_kernel<1, false>); }
-    else        { if (wreg) launch(lstm_bwd_persist_rs_kernel<2, true>); else launch(lstm_bwd_persist_rs_kernel<2, false>); }
+    // ARCVAE_RS_MFMA: 1 (default) = 4x4x1 blocks, 0 = 16x16x4 tiles (registers only; the LDS variant always uses 16x16x4)
+    const bool mf = wreg && arcvae_env_int("ARCVAE_RS_MFMA", 1) != 0;
+    if (L == 1) {
+        if (mf) launch(lstm_bwd_persist_rs_kernel<1, true, 1>);
+        else if (wreg) launch(lstm_bwd_persist_rs_kernel<1, true, 0>);
+        else launch(lstm_bwd_persist_rs_kernel<1, false, 0>);
+    } else {
+        if (mf) launch(lstm_bwd_persist_rs_kernel<2, true, 1>);
+        else if (wreg) launch(lstm_bwd_persist_rs_kernel<2, true, 0>);
+        else launch(lstm_bwd_persist_rs_kernel<2, false, 0>);
+    }
     return arcvae_launch_status();
 }
 
