@@ -224,6 +224,14 @@ def main():
         torch.cuda.synchronize()
         emit(json.dumps({"roofline": roofline_probe(eng, ws, torch)}))
         return
+    # The host enqueues a step in less than half its device time, but only a few steps ahead: a generational GC pass over
+    # the heap torch leaves behind (~10 ms) lands on the device timeline as a stall.  The loop below allocates nothing
+    # that needs cycle collection.  (ARCVAE_BENCH_GC=1 leaves the collector on.)
+    if os.environ.get("ARCVAE_BENCH_GC", "0") == "0":
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
     log(f"rank {rank}/{world}: warm-up ({args.warmup} steps, mode={mode})")
     fallback = None
     for attempt in range(3):
@@ -264,11 +272,20 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_enq = 0.0
+    marks = []                                       # ARCVAE_BENCH_INTERVALS=n: an event every n steps (diagnostics)
+    every = int(os.environ.get("ARCVAE_BENCH_INTERVALS", "0"))
     for i in range(args.warmup, total):
+        if every and (i - args.warmup) % every == 0:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
         h0 = time.perf_counter()
         one_step(i)
         host_enq += time.perf_counter() - h0
     torch.cuda.synchronize()
+    if len(marks) > 1:
+        log("ms/step per interval: " + " ".join(f"{marks[k].elapsed_time(marks[k + 1]) / every:.3f}"
+                                                for k in range(len(marks) - 1)))
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0

@@ -456,6 +456,10 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     if nc + 1 > g.STRIDE:
         raise ValueError("too many BPTT chunks for the gate stride")
     tail_on_side = aux2 is not None and nc >= 2
+    # Since the persistent sweeps the weight-gradient stream, not the chain, ends the step (aux is busy without a gap
+    # from the end of chunk 0 to the end of the step): the token-table half of EVERY chunk goes to side, which is idle
+    # once the decoder is done (ARCVAE_TABLE_ON_SIDE=0: only the tail chunk's, as before).
+    table_on_side = tail_on_side and os.environ.get("ARCVAE_TABLE_ON_SIDE", "1") != "0"
 
     def main_seg():
         # the whole critical chain of the backward as ONE captured segment: the "chunk c done" signal is raised by
@@ -476,19 +480,23 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             g.wait(g.P, g.NA, g.STRIDE, g.STRIDE if last else 2 + c, advance=last)
             if c == 0:
                 plan.heads(2)
-            plan.wgrad(t_lo, t_hi, first, last, 1 if (last and tail_on_side) else 3)
+            plan.wgrad(t_lo, t_hi, first, last, 1 if (table_on_side or (last and tail_on_side)) else 3)
             if c == max(nc - 2, 0):
                 g.signal(g.Q, 1)
             if last:
                 g.signal(g.R, 1 if tail_on_side else 2)
 
-        def side_seg(t_lo=t_lo, t_hi=t_hi, first=first, last=last):
-            g.wait(g.Q, g.NS, 1, 1)
-            g.wait(g.P, g.NS, g.STRIDE, g.STRIDE, advance=True)
+        def side_seg(c=c, t_lo=t_lo, t_hi=t_hi, first=first, last=last):
+            if table_on_side:   # the table accumulates on side only: chunk c behind main's signal #(2+c), as aux
+                g.wait(g.P, g.NS, g.STRIDE, g.STRIDE if last else 2 + c, advance=last)
+            else:
+                g.wait(g.Q, g.NS, 1, 1)
+                g.wait(g.P, g.NS, g.STRIDE, g.STRIDE, advance=True)
             plan.wgrad(t_lo, t_hi, first, last, 2)
-            g.signal(g.R, 1)
+            if last:
+                g.signal(g.R, 1)
 
-        if last and tail_on_side:
+        if table_on_side or (last and tail_on_side):
             run(f"aux2_{c}", side_seg, aux2)
         run(f"aux{c}", aux_seg, aux)
     if aux2 is not None and not tail_on_side:

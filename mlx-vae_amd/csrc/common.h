@@ -69,13 +69,13 @@ __device__ __forceinline__ void arcvae_set_prio(int p) {
 // Accurate (non fast-math) transcendental forms: parity mode needs ~1-2 ulp expf/tanhf.
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Activations of the PERSISTENT sweeps, where one wave per layer evaluates them on the dependent chain of every tick:
-// the libm forms cost ~180 VALU instructions per cell (3 sigmoids of ~30, 2 tanh of ~43), ~0.3 us of a 3.6 us tick.
-// Hardware forms instead: v_exp_f32 / v_rcp_f32 are 1-ulp instructions; sigmoid = rcp(1 + exp2(-x log2 e)) stays within
-// ~4e-7 relative; tanh = (1 - e) / (1 + e), e = exp(-2|x|), and an odd polynomial below |x| = 0.25 where that quotient
-// would lose relative accuracy to cancellation (truncation 8e-9): ~3e-7 relative everywhere.  Three orders below the
-// 1e-4 parity bar.  -DARCVAE_ACCURATE_ACT restores the libm forms.
-#ifdef ARCVAE_ACCURATE_ACT
+// Activations of the PERSISTENT sweeps, where one wave per layer evaluates them on the dependent chain of every tick.
+// Default: the libm forms (~180 VALU instructions per cell: 3 sigmoids of ~30, 2 tanh of ~43).  -DARCVAE_CHAIN_FAST_ACT
+// switches to hardware forms (v_exp_f32 / v_rcp_f32 are 1-ulp instructions; sigmoid = rcp(1 + exp2(-x log2 e)), ~4e-7
+// relative; tanh = (1 - e) / (1 + e), e = exp(-2|x|), with an odd polynomial below |x| = 0.25 where the quotient loses
+// relative accuracy to cancellation: ~3e-7 relative everywhere, parity-green at 1e-4).  Measured on one box, A/B of the
+// two libraries: 1.308 vs 1.300 ms and 1.101 vs 1.107 ms per step -- no gain beyond noise, so the accurate forms stay.
+#ifndef ARCVAE_CHAIN_FAST_ACT
 __device__ __forceinline__ float chain_sigmoid(float x) { return sigmoidf_acc(x); }
 __device__ __forceinline__ float chain_tanh(float x) { return tanhf(x); }
 #else

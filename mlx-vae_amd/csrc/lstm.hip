@@ -744,8 +744,16 @@ __device__ __forceinline__ unsigned ps_xcc_id() {
 
 constexpr bool persist_wreg(int NT, int LL) { return (2 * LL - 1) * (2 * NT) * NT <= 32; }
 
-template <int NT, int LL, int RT>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
+// MF = 1 (H = 256, at most 8 rows per XCD, L <= 2): the contraction on v_mfma_f32_4x4x1 blocks instead of 16x16x4 tiles.
+// With 8 rows a 16-row tile is half empty: 96 instructions of 32 cycles per wave and tick, 1.28 us of the tick, for
+// half that much useful work.  Blocks = 2 row groups x 8 column groups: ONE 4x4x1 instruction (8 cycles) is the rank-1
+// update of the CU's whole 8 x 32 output for one k -- 192 instructions per wave and tick, 0.64 us.  h is the A operand:
+// a lane loads 4 consecutive k of its row (block cg holds k = 4cg .. 4cg+3), and the instruction's A-broadcast
+// (cbsz = 3, abid = source block) hands one block's values to the 8 blocks of its row group, so the operand is loaded
+// once, without padded rows (2 16-byte loads per source instead of 4).  Weights are the B operand, 192 VGPRs.
+template <int NT, int LL, int RT, int MF = 0>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
 __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
+    static_assert(MF == 0 || (NT == 2 && RT == 1 && LL <= 2), "4x4x1 form: H = 256, one row tile, L <= 2");
     constexpr int CW = 16 * NT;          // gate columns per CU
     constexpr int UW = 4 * NT;           // hidden units per CU
     constexpr int NCH = 8 * NT;          // 16-wide k-chunks of a source (H / 16)
@@ -757,7 +765,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     // S * CHW * NT float4 per lane) is at most 32 float4 = 128 VGPRs -- the default shape needs 24 -- else in LDS.
     // Registers take the 96 KB of LDS reads per tick off the LDS pipe (which the GEMM blocks sharing the CU also use):
     // 1.400 -> 1.382 ms per step at the default shape (A/B on one box).
-    constexpr bool WREG = persist_wreg(NT, LL) && RT == 1;   // two row tiles: 288 VGPRs and 0.8 % slower than LDS
+    constexpr bool WREG = (persist_wreg(NT, LL) && RT == 1) || MF;   // two row tiles: 288 VGPRs and 0.8 % slower than LDS
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                                 // [S][NCH][CW][16]   (LDS variant only)
     float* red = WREG ? lds : lds + S * NCH * CW * 16;   // [4 waves][LL][16*RT][CW]
@@ -782,10 +790,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
     // stationary weights: permuted rows [role*CW, +CW) of every source
     const int r = lane & 15, q4 = (lane >> 4) * 4;
-    f32x4 wr[WREG ? S : 1][WREG ? CHW : 1][WREG ? NT : 1];
+    const int rg = lane >> 5, cg = (lane >> 2) & 7, ij = lane & 3;   // 4x4x1 blocks: (row group, column group), index in block
+    f32x4 wr[(WREG && !MF) ? S : 1][(WREG && !MF) ? CHW : 1][(WREG && !MF) ? NT : 1];
+    f32x4 wq[MF ? S : 1][MF ? CHW : 1][MF ? 4 : 1];   // [source][16-wide k chunk of my quarter][4-group]: W[k..k+3][4cg + ij]
     {
         const long wsz = (long)H * G;
-        if constexpr (WREG) {
+        if constexpr (MF == 1) {
+#pragma unroll
+            for (int si = 0; si < S; ++si)
+#pragma unroll
+                for (int c = 0; c < CHW; ++c)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        wq[si][c][g4] = *reinterpret_cast<const f32x4*>(
+                            a.wt + si * wsz + ((long)(wave * CHW + c) * G + role * CW + 4 * cg + ij) * 16 + 4 * g4);
+        } else if constexpr (WREG) {
 #pragma unroll
             for (int si = 0; si < S; ++si)
 #pragma unroll
@@ -808,6 +827,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     int arow[RT];                                               // tile rows beyond this XCD's rows repeat the last one
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) arow[rt] = min(row0 + min(16 * rt + r, RX - 1), B - 1);
+    const int mrow = min(row0 + min(4 * rg + ij, RX - 1), B - 1);   // 4x4x1 form: the row of this lane's A values
     // epilogue ownership: layer el, pairs p = tl + i*TPL of the RX x UW (row, unit) pairs of this block
     const int el = min(tid / TPL, LL - 1), tl = tid - el * TPL;
     const bool eactive = tid < LL * TPL;
@@ -863,6 +883,49 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             if (!s_ok) return;
         }
         if (tr) a.trace[2 * s] = wall_clock64();
+        if constexpr (MF == 1) {
+            // ---- A operands: 4 consecutive k of my row per load; block cg of my row group holds k = 64w + 32m + 4cg + e
+            f32x4 qx[LL][2], qh[LL][2];
+#pragma unroll
+            for (int l = 0; l < LL; ++l) {
+                const int t = s - l;
+                const bool act = t >= 0 && t < T;
+                if (act && l > 0) {
+                    const float* p = a.hseq + (l - 1) * lH + (long)t * sH + (long)mrow * H + 64 * wave + 4 * cg;
+                    qx[l][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+                    qx[l][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32));
+                }
+                if (act && t > 0) {
+                    const float* p = a.hseq + l * lH + (long)(t - 1) * sH + (long)mrow * H + 64 * wave + 4 * cg;
+                    qh[l][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+                    qh[l][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32));
+                }
+            }
+            // ---- rank-1 updates: for every k of my quarter, the A values of block (k >> 2) & 7 broadcast to its row group
+#pragma unroll
+            for (int l = 0; l < LL; ++l) {
+                const int t = s - l;
+                if (t < 0 || t >= T) continue;            // block-uniform
+                f32x4 acc[4];                              // four independent chains (one per k mod 4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define PS_Q1(Q, SIDX, M_, AB_)                                                                                          \
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].x, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].x, acc[0], 3, AB_, 0); \
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].y, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].y, acc[1], 3, AB_, 0); \
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].z, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].z, acc[2], 3, AB_, 0); \
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].w, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].w, acc[3], 3, AB_, 0);
+#define PS_Q8(Q, SIDX, M_) PS_Q1(Q, SIDX, M_, 0) PS_Q1(Q, SIDX, M_, 1) PS_Q1(Q, SIDX, M_, 2) PS_Q1(Q, SIDX, M_, 3) \
+                           PS_Q1(Q, SIDX, M_, 4) PS_Q1(Q, SIDX, M_, 5) PS_Q1(Q, SIDX, M_, 6) PS_Q1(Q, SIDX, M_, 7)
+                if (l > 0) { PS_Q8(qx, LL + l - 1, 0) PS_Q8(qx, LL + l - 1, 1) }
+                if (t > 0) { PS_Q8(qh, l, 0) PS_Q8(qh, l, 1) }
+#undef PS_Q8
+#undef PS_Q1
+                // lane (rg, cg, ij) holds rows 4rg + i (register i) of column 4cg + ij
+                float* rp = red + wave * RW + l * 16 * RT * CW + (4 * rg) * CW + 4 * cg + ij;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rp[i * CW] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+            }
+        } else {
         // ---- A operands: rows of my XCD from the slabs the previous tick wrote (L1-bypassing loads)
         f32x4 fx[LL][RT][CHW], fh[LL][RT][CHW];
 #pragma unroll
@@ -923,6 +986,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                     for (int reg = 0; reg < 4; ++reg)
                         rp[(16 * rt + (lane >> 4) * 4 + reg) * CW + 16 * n + r] = acc[rt][n][reg];
         }
+        }
         __syncthreads();
         // ---- cell update of my (row, unit) pairs; c stays in a register from tick to tick.  (Storing the saved gates
         // and c after the flag, under the next tick's barrier wait, was measured: no gain.)
@@ -963,22 +1027,25 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     }
 }
 
-template <int NT, int LL, int RT>
+template <int NT, int LL, int RT, int MF = 0>
 void launch_persist(const PersistArgs& a, size_t lds, hipStream_t s) {
     static bool attr_set = false;   // > 64 KB of dynamic LDS has to be allowed once per kernel (first call: eager step)
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL, RT>,
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL, RT, MF>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL, RT>), dim3(256), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL, RT, MF>), dim3(256), dim3(256), lds, s, a);
 }
 inline int persist_row_tiles(int B) { return ceil_div(B, 8) > 16 ? 2 : 1; }
+// LDS allocation floor of the register-stationary persistent kernels (ARCVAE_PERSIST_LDS_KB, default 81 = more than half
+// of a CU's 160 KB): two of their blocks can then never share a CU, whatever else is resident.
+inline size_t persist_lds_floor() { return (size_t)arcvae_env_int("ARCVAE_PERSIST_LDS_KB", 81) * 1024; }
 inline size_t persist_lds_bytes(int B, int H, int L) {
     const int NT = H / 128, CW = 16 * NT;
     const size_t red = sizeof(float) * (size_t)4 * L * 16 * persist_row_tiles(B) * CW;
     if (persist_wreg(NT, L) && persist_row_tiles(B) == 1)   // weights in registers: only the reduction buffer is used, but the allocation stays above
-        return red > 81 * 1024 ? red : 81 * 1024;   // half the CU's LDS so that the blocks land one per CU
+        return red > persist_lds_floor() ? red : persist_lds_floor();   // half the CU's LDS so that the blocks land one per CU
     return sizeof(float) * (size_t)(2 * L - 1) * (H / 16) * CW * 16 + red;
 }
 // up to 32 rows per XCD (two MFMA row tiles): B <= 256, i.e. also the 256-row shard of BASELINE.json configs[3]
@@ -1673,7 +1740,10 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
     const int RTn = persist_row_tiles(B);
 #define PS_LAUNCH(N_, L_) do { if (RTn == 2) launch_persist<N_, L_, 2>(a, lds, stream); else launch_persist<N_, L_, 1>(a, lds, stream); } while (0)
 #define PS_BY_L(N_) switch (L) { case 1: PS_LAUNCH(N_, 1); break; case 2: PS_LAUNCH(N_, 2); break; case 3: PS_LAUNCH(N_, 3); break; default: PS_LAUNCH(N_, 4); break; }
-    if (NT == 1) { PS_BY_L(1) } else if (NT == 2) { PS_BY_L(2) } else { PS_BY_L(3) }
+    // ARCVAE_FWD_MFMA: 1 (default) = 4x4x1 blocks where the shape allows (H 256, <= 8 rows per XCD, L <= 2), 0 = 16x16x4
+    if (NT == 2 && L <= 2 && a.RX <= 8 && arcvae_env_int("ARCVAE_FWD_MFMA", 1) != 0) {
+        if (L == 1) launch_persist<2, 1, 1, 1>(a, lds, stream); else launch_persist<2, 2, 1, 1>(a, lds, stream);
+    } else if (NT == 1) { PS_BY_L(1) } else if (NT == 2) { PS_BY_L(2) } else { PS_BY_L(3) }
 #undef PS_BY_L
 #undef PS_LAUNCH
     return arcvae_launch_status();
@@ -1761,7 +1831,7 @@ extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, co
     // ARCVAE_RS_WREG=0: weight slices in LDS instead of registers.  Either way at least 81 KB of LDS: one block per CU.
     const bool wreg = arcvae_env_int("ARCVAE_RS_WREG", 1) != 0;
     size_t lds = sizeof(float) * ((wreg ? 0 : (size_t)(2 * L - 1) * 256 * 36) + (size_t)L * 16 * 32 + 128);
-    if (lds < 81 * 1024) lds = 81 * 1024;
+    if (lds < persist_lds_floor()) lds = persist_lds_floor();
     auto launch = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, stream, ar);
