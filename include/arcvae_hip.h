@@ -107,7 +107,9 @@ int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* 
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,
  * lstm_layer_l.{Wx,Wh,bias}; `first` zeroes the token-table workspace, `last` folds it into the
  * embedding / layer-0 gradients.  dtable_ws [V,4H]; onehot_ws [T*B, roundup(V,4)] (one-hot token rows, written
- * when `first`: the token segment-sum runs as OneHot^T . dG_0 on the matrix cores). */
+ * when `first`: the token segment-sum runs as OneHot^T . dG_0 on the matrix cores).  `parts` selects disjoint pieces
+ * that may run on different streams: bit 0 = per-layer GEMMs and bias sums (= bits 2 | 3), bit 1 = token-table path,
+ * bit 2 = dWx_l (l >= 1) and bias sums only, bit 3 = dWh_l only. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
                           const float* dG, float* dtable_ws, float* onehot_ws, float* dEmb, float* const* dWx,
                           float* const* dWh, float* const* dbias, int B, int T, int V, int E, int H, int L,

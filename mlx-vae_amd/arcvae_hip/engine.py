@@ -330,11 +330,21 @@ class EncoderBackwardPlan:
     completes its time range.  Chunks shrink geometrically so the part of the weight-gradient work that
     cannot overlap the sweep (the last chunk) is small."""
 
-    FRACTIONS = tuple(float(f) for f in os.environ.get("ARCVAE_BPTT_CHUNKS", "0.3,0.6,0.85,1.0").split(","))
+    # Chunk boundaries as fractions of the sweep (ARCVAE_BPTT_CHUNKS overrides both).  Launch-based sweep: four chunks.
+    # Persistent sweep: two -- every chunk is a relaunch of a kernel that needs all 256 CUs at once, and whatever runs
+    # beside the sweep slows its ticks (2.6 us alone, 3.6 with the weight-gradient GEMMs on the same CUs), so the
+    # gradient GEMMs are better concentrated late and spread over two streams (measured on one box, steady state:
+    # 4 chunks 1.073-1.078 ms, "0.5,0.85,1" 1.069, two chunks at 0.5 / 0.6 / 0.65 / 0.7 / 0.8 of the sweep with the
+    # dWx GEMMs on side 1.060 / 1.040-1.044 / 1.037 / 1.045 / 1.051).
+    FRACTIONS_LAUNCHES = "0.3,0.6,0.85,1.0"
+    FRACTIONS_PERSISTENT = "0.63,1.0"
 
     def __init__(self, enc: ParamStore, ws: Workspace, d: ModelDims):
         self.enc, self.ws, self.d = enc, ws, d
         L, T = d.L, ws.T
+        self.persistent = bptt_reduce_scatter_ok(ws, d)
+        self.FRACTIONS = tuple(float(f) for f in os.environ.get(
+            "ARCVAE_BPTT_CHUNKS", self.FRACTIONS_PERSISTENT if self.persistent else self.FRACTIONS_LAUNCHES).split(","))
         self.S = T + 2 * (L - 1)  # launches of the BPTT wavefront (csrc/lstm.hip)
         self._wx = _layer_ptrs(enc, L, "Wx", skip0=True)
         self._wh = _layer_ptrs(enc, L, "Wh")
@@ -363,7 +373,7 @@ class EncoderBackwardPlan:
         # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
         sig = start_signal if start_signal is not None else C.c_void_p(0)
-        if bptt_reduce_scatter_ok(ws, d):
+        if self.persistent:
             # latency regime, default shape: persistent BPTT sweep in its reduce-scatter form, one launch per chunk
             # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
             call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
@@ -460,6 +470,11 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     # from the end of chunk 0 to the end of the step): the token-table half of EVERY chunk goes to side, which is idle
     # once the decoder is done (ARCVAE_TABLE_ON_SIDE=0: only the tail chunk's, as before).
     table_on_side = tail_on_side and os.environ.get("ARCVAE_TABLE_ON_SIDE", "1") != "0"
+    # ... and, beside a persistent sweep, the dWx_l GEMMs and the bias sums too (a third of aux's GEMM work; disjoint
+    # outputs): two grouped launches in flight.  With the four chunks of the launch-based sweep this was 1 % slower
+    # (1.084-1.088 vs 1.073 ms); with the two late chunks of the persistent sweep it is what makes them pay
+    # (ARCVAE_WX_ON_SIDE=0/1 overrides).
+    wx_on_side = table_on_side and os.environ.get("ARCVAE_WX_ON_SIDE", "1" if plan.persistent else "0") != "0"
 
     def main_seg():
         # the whole critical chain of the backward as ONE captured segment: the "chunk c done" signal is raised by
@@ -480,7 +495,8 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             g.wait(g.P, g.NA, g.STRIDE, g.STRIDE if last else 2 + c, advance=last)
             if c == 0:
                 plan.heads(2)
-            plan.wgrad(t_lo, t_hi, first, last, 1 if (table_on_side or (last and tail_on_side)) else 3)
+            plan.wgrad(t_lo, t_hi, first, last,
+                       8 if wx_on_side else (1 if (table_on_side or (last and tail_on_side)) else 3))
             if c == max(nc - 2, 0):
                 g.signal(g.Q, 1)
             if last:
@@ -492,7 +508,7 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             else:
                 g.wait(g.Q, g.NS, 1, 1)
                 g.wait(g.P, g.NS, g.STRIDE, g.STRIDE, advance=True)
-            plan.wgrad(t_lo, t_hi, first, last, 2)
+            plan.wgrad(t_lo, t_hi, first, last, 6 if wx_on_side else 2)
             if last:
                 g.signal(g.R, 1)
 

@@ -736,6 +736,13 @@ struct PersistArgs {
     int B, T, H, V, RX, prio;
 };
 
+// "My stores are in the XCD's L2" -- what the flag protocol of the persistent kernels needs before a flag may be raised.
+// A workgroup-scope release fence is NOT that: on gfx942/gfx950 (not in tgsplit mode) the compiler emits no vmcnt wait
+// for it (waves of a workgroup share their CU's L1), so the flag -- a different L2 channel than the data -- could
+// overtake the data it announces: seen as 1e-3-level deviations in the layer-0 gradients of ~1 step in 4 beside busy
+// GEMM streams (tools/race_hunt.py).  vmcnt counts a store until the L2 has acknowledged it.
+__device__ __forceinline__ void ps_stores_in_l2() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ unsigned ps_xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                 a.cseq[el * lH + (long)te * sH + hb] = c;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): my h stores have reached the L2
+        ps_stores_in_l2();                                       // my h stores have reached the XCD's L2
         __syncthreads();
         if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (tr) a.trace[2 * s + 1] = wall_clock64();
@@ -1274,7 +1281,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my dG stores have reached the XCD's L2
+        ps_stores_in_l2();                                       // my dG stores have reached the XCD's L2
         __syncthreads();
         if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (tr) a.trace[2 * s + 1] = wall_clock64();
@@ -1489,7 +1496,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             }
                     }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my partials have reached the XCD's L2
+        ps_stores_in_l2();                                       // my partials have reached the XCD's L2
         __syncthreads();
         if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // ---- every CU of my XCD has published its partials of tick s
@@ -1952,7 +1959,8 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   l >= 1: dWx_l += dG_l[t]^T . hseq_{l-1}[t];  all l: dWh_l += dG_l[t]^T . hseq_l[t-1] (t >= 1);  dbias_l += colsum
 //   l == 0: dTable0[v] += sum_{(t,b): x=v} dG_0[t,b]   (dtable_ws [V,4H], zeroed when `first` != 0)
 //   when `last` != 0 (all ranges done): dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;  dbias_0 += colsum(dTable0)
-//   parts: bit 0 = the per-layer GEMMs, bit 1 = the layer-0 token-table path (they are independent: two streams)
+//   parts: bit 0 = the per-layer GEMMs (= bits 2 | 3), bit 1 = the layer-0 token-table path, bit 2 = only the dWx_l
+//   GEMMs (l >= 1) and the bias column sums, bit 3 = only the dWh_l GEMMs (disjoint outputs: up to three streams)
 //   onehot_ws [T*B, roundup(V,4)] workspace: one-hot token rows, written when `first` != 0 (token-table part)
 extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0,
                                      const float* hseq, const float* dG, float* dtable_ws, float* onehot_ws,
@@ -1965,7 +1973,8 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     const int G = 4 * H, TB = T * B;
     const long lH = (long)TB * H, lG = (long)TB * G;
     int rc;
-    const bool do_layers = (parts & 1) != 0, do_table = (parts & 2) != 0;
+    const bool do_wx = (parts & (1 | 4)) != 0, do_wh = (parts & (1 | 8)) != 0, do_table = (parts & 2) != 0;
+    const bool do_layers = do_wx || do_wh;
     const int Vp = (V + 3) & ~3;
     if (do_table && first) {
         if (arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
@@ -1984,11 +1993,11 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
             const int t1 = t_lo > 1 ? t_lo : 1;  // dWh pairs dG[t] with h[t-1]
             for (int l = 0; l < L; ++l) {
                 const float* dGl = dG + l * lG;
-                if (t_hi > t1) {
+                if (do_wh && t_hi > t1) {
                     Ag[n] = dGl + (long)t1 * B * G; Bg[n] = hseq + l * lH + (long)(t1 - 1) * B * H;
                     Cg[n] = dWh[l]; Kg[n] = (t_hi - t1) * B; ++n;
                 }
-                if (l > 0) {
+                if (do_wx && l > 0) {
                     Ag[n] = dGl + (long)t_lo * B * G; Bg[n] = hseq + (l - 1) * lH + (long)t_lo * B * H;
                     Cg[n] = dWx[l]; Kg[n] = nt * B; ++n;
                 }
@@ -1998,7 +2007,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                                                 stream);
                 if (rc) return rc;
             }
-            for (int l = 1; l < L; ++l) {
+            for (int l = 1; l < L && do_wx; ++l) {
                 rc = arcvae_colsum_accum(dG + l * lG + (long)t_lo * B * G, nt * B, G, G, dbias[l], 1.0f, stream);
                 if (rc) return rc;
             }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
             for (int s = 0; s < NSRC; ++s)
                 if (col < 8) ho[((long)s * 64 + xcc * ROWS + row) * H + role * 8 + col] = cst;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): my stores have reached L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my stores have reached L2 (a workgroup-scope release fence emits no vmcnt wait)
         __syncthreads();
         if (tid == 0) __hip_atomic_store(a.flags + xcc * 32 + role, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store: stays in the XCD's L2
     }
