@@ -297,6 +297,34 @@ def test_default_model_large_batches_kernel_families_agree(B, monkeypatch):
     assert rel_err(a[1], b[1]) < 1e-4
 
 
+@pytest.mark.parametrize("H,L,B,T", [(256, 2, 64, 12), (256, 2, 64, 40), (128, 2, 24, 10)])
+def test_persistent_sweeps_are_repeatable(H, L, B, T):
+    """Ordering check of the persistent sweeps' flag protocol (csrc/lstm.hip: ps_stores_in_l2): the same step, repeated
+    with the decoder and the weight-gradient GEMMs busy on the other streams, must give the same forward activations bit
+    for bit (the forward sweep has no atomics) and the same encoder gradients up to the split-K atomics' rounding.
+    Before the explicit vmcnt(0) a flag could overtake the data it announces: ~1 step in 4 came out with 1e-3-level
+    deviations in the layer-0 gradients (tools/race_hunt.py; profiles/r01_race_hunt_before_fix.txt)."""
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=1, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    eng, enc, dec = build_engine(cfg, params)
+    names = ["lstm_layer_0.Wh", "lstm_layer_0.bias", f"lstm_layer_{L - 1}.Wh", "embedding.weight"]
+    ref = None
+    for it in range(300):
+        eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+        torch.cuda.synchronize()
+        ws = eng.workspace(B, T, True)
+        cur = {n: enc.g(n).clone() for n in names}
+        h = ws.hseq.clone()
+        if ref is None:
+            ref, refh = cur, h
+            continue
+        assert torch.equal(h, refh), f"step {it}: forward activations differ"
+        for n in names:
+            dev = float((cur[n] - ref[n]).abs().max() / ref[n].abs().max())
+            assert dev < 2e-5, (it, n, dev)
+    eng.check_gates()
+
+
 @pytest.mark.parametrize("env", [{"ARCVAE_PERSIST": "0"}, {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "1"},
                                  {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "0"}, {"ARCVAE_PERSIST": "1"}])
 @pytest.mark.parametrize("H,L,B,T,C", [(128, 2, 20, 9, 1), (128, 1, 33, 7, 2), (256, 2, 64, 12, 1), (384, 1, 9, 5, 1),

@@ -26,8 +26,9 @@ for name, cs in sorted(acc.items()):
     if "WRITE_SIZE" in avg: e["WRITE_SIZE_KB_avg"] = avg["WRITE_SIZE"]
     if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
         e["bytes_per_launch"] = 1024.0 * (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"])
-        if name == "lstm_bwd_persist_rs_kernel":   # one launch per BPTT chunk: 130 ticks in 4 launches at the default shape
-            e["bytes_per_tick"] = e["bytes_per_launch"] * 4.0 / 130.0
+        if name == "lstm_bwd_persist_rs_kernel":   # one launch per BPTT chunk: 130 ticks in CHUNKS launches at the default shape
+            chunks = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+            e["bytes_per_tick"] = e["bytes_per_launch"] * chunks / 130.0
     if "_mfma_frac" in avg:
         e["mfma_busy_frac"] = avg["_mfma_frac"]
         e["mfma_busy_cycles_avg"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"]
