@@ -294,7 +294,22 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     scal = ws.scalars.cpu().numpy()
-    eng.check_gates()  # a device-side gate that gave up waiting would mean the streams lost their order
+    # a device-side gate or a persistent sweep that gave up waiting would mean the streams lost their order: no number
+    # then -- and every rank leaves together (a lone exit would park the others in the barrier below)
+    bad, why = 0, ""
+    try:
+        eng.check_gates()
+    except _lib.ArcvaeHipError as e:
+        bad, why = 1, str(e)
+        log(f"rank {rank}: {why}")
+    if world > 1:
+        bt = torch.tensor([bad], device=dev, dtype=torch.int32)
+        dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        bad = int(bt.item())
+    if bad:
+        if use_dp:
+            dist.destroy_process_group()
+        raise SystemExit("bench.py: stream ordering was lost during the timed steps " + why)
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
