@@ -4,7 +4,10 @@
 // the per-tick barrier spans the 32 CUs of one XCD only (a flag line in that L2), never the chip.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probe_persist.hip -o gpurun_out/probe_persist
 // Shape: H = 256, 3 sources per tick (Wh0, Wx1, Wh1 as in the 2-layer forward wavefront), 8 rows per XCD (B = 64),
-// 32 gate columns (8 units) per CU.  MODE: 0 barrier only, 1 + A loads, 2 + MFMA (W from LDS), 3 + reduce/cell/stores.
+// 32 gate columns (8 units) per CU.  MODE: 0 barrier only, 1 + A loads, 2 + MFMA (W from LDS), 3 + reduce/cell/stores,
+// 4 = the full tick WITHOUT flags: the exchanged values carry their own sequence tag (8-byte {value, tick} stores, the
+// consumer re-polls its operand lines until every tag is the tick it expects) -- no store wait, no flag line, no
+// per-XCD barrier (DESIGN.md section 9, next lever 1; written at the end of round 1, not yet run on the GPU).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -12,12 +15,14 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int H = 256, NSRC = 3, ROWS = 8, COLS = 32, NXCD = 8, NCU = 32;
 
 struct Args {
     const float* W;      // [NSRC][4H rows][H] k-chunk-major: [src][k/16][4H][16]
     float* hbuf;         // [2 slots][NSRC][64 rows][H]  (A operands of the next tick)
+    uint2* hx;           // MODE 4: the same slots as {value bits, tag} pairs; tag = tick that consumes the value
     unsigned* flags;     // [NXCD][32]   (one 128-B line per XCD)
     unsigned* cnt;       // [NXCD] role counters
     unsigned* info;      // [256][2] (xcc, role) per block
@@ -60,6 +65,59 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
     const int arow = xcc * ROWS + (r & 7);          // rows 8..15 of the MFMA tile repeat rows 0..7 (ignored)
     float cst = 0.f;                                // cell state of my (row, unit) stays in a register
     for (int t = 0; t < a.T; ++t) {
+        if (MODE == 4) {
+            // ---- tagged exchange: my A operands ARE the synchronisation.  Lane (r, q4) of wave w needs k = 16c + q4 .. +3
+            // of its row for its 4 chunks: 4 pairs = 32 B = two 16-byte loads per chunk and source.
+            const uint2* hb = a.hx + (long)(t & 1) * NSRC * 64 * H;
+            f32x4 fa[NSRC][4];
+            unsigned spins = 0;
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x4* p = reinterpret_cast<const u32x4*>(hb + ((long)s * 64 + arow) * H + (wave * 4 + c) * 16 + q4);
+                        const u32x4 lo = __builtin_nontemporal_load(p), hi = __builtin_nontemporal_load(p + 1);
+                        fa[s][c] = f32x4{__uint_as_float(lo.x), __uint_as_float(lo.z), __uint_as_float(hi.x), __uint_as_float(hi.z)};
+                        ok = ok && lo.y == (unsigned)t && lo.w == (unsigned)t && hi.y == (unsigned)t && hi.w == (unsigned)t;
+                    }
+                if (__all(ok)) break;
+                if (++spins > 200000u) { if (lane == 0) atomicAdd(a.err, 1u); return; }   // every wave gives up on its own
+            }
+            f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int kc = wave * 4 + c;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wl + (((long)s * 16 + kc) * COLS + 16 * n + r) * 16 + q4);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][c].x, w.x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][c].y, w.y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][c].z, w.z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][c].w, w.w, acc[n], 0, 0, 0);
+                    }
+                }
+            __syncthreads();                       // red of the previous tick has been read by everybody
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) red[wave * 512 + ((lane >> 4) * 4 + reg) * 32 + 16 * n + r] = acc[n][reg];
+            __syncthreads();
+            {
+                const int row = tid >> 5, col = tid & 31;
+                float v = (red[row * 32 + col] + red[512 + row * 32 + col]) + (red[1024 + row * 32 + col] + red[1536 + row * 32 + col]);
+                const float g = tanhf(v * 0.01f);
+                cst = 0.5f * cst + g;
+                uint2* ho = a.hx + (long)((t + 1) & 1) * NSRC * 64 * H;
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s)       // one 8-byte store per value: the tag arrives with it or not at all
+                    if (col < 8) ho[((long)s * 64 + xcc * ROWS + row) * H + role * 8 + col] = make_uint2(__float_as_uint(cst), (unsigned)(t + 1));
+            }
+            continue;
+        }
         // ---- wait until all 32 CUs of my XCD have published tick t-1
         if (t > 0) {
             if (wave == 0) {
@@ -144,11 +202,13 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
 template <int MODE>
 int run(const char* name, Args a, int lds_bytes) {
     CK(hipMemset(a.flags, 0, NXCD * 32 * 4)); CK(hipMemset(a.cnt, 0, NXCD * 4)); CK(hipMemset(a.err, 0, 4));
+    CK(hipMemset(a.hx, 0, (size_t)2 * NSRC * 64 * H * 8));      // tag 0 = what tick 0 expects
     CK(hipFuncSetAttribute((const void*)persist_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(persist_kernel<MODE>, dim3(256), dim3(256), lds_bytes, 0, a);   // warm-up
     CK(hipDeviceSynchronize());
     CK(hipMemset(a.flags, 0, NXCD * 32 * 4)); CK(hipMemset(a.cnt, 0, NXCD * 4));
+    CK(hipMemset(a.hx, 0, (size_t)2 * NSRC * 64 * H * 8));
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(persist_kernel<MODE>, dim3(256), dim3(256), lds_bytes, 0, a);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
@@ -166,6 +226,7 @@ int main() {
     std::vector<float> hw((size_t)NSRC * 4 * H * H); for (auto& x : hw) x = (rand() % 2001 - 1000) * 1e-4f;
     CK(hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&a.hbuf, (size_t)2 * NSRC * 64 * H * 4)); CK(hipMemset(a.hbuf, 0, (size_t)2 * NSRC * 64 * H * 4));
+    CK(hipMalloc(&a.hx, (size_t)2 * NSRC * 64 * H * 8));
     CK(hipMalloc(&a.flags, NXCD * 32 * 4)); CK(hipMalloc(&a.cnt, NXCD * 4)); CK(hipMalloc(&a.info, 256 * 2 * 4)); CK(hipMalloc(&a.err, 4));
     a.W = W;
     const int lds_bytes = (NSRC * 16 * COLS * 16 + 4 * 16 * 32) * 4;
@@ -174,5 +235,6 @@ int main() {
     if (run<1>("+ A operand loads (L1-bypassing)", a, lds_bytes)) return 1;
     if (run<2>("+ 96 MFMAs per wave, W from LDS", a, lds_bytes)) return 1;
     if (run<3>("+ reduce, cell update, h stores (full tick)", a, lds_bytes)) return 1;
+    if (run<4>("full tick, tagged exchange (no flags)", a, lds_bytes)) return 1;
     return 0;
 }
