@@ -351,14 +351,23 @@ class EncoderBackwardPlan:
         self._dwx = _layer_ptrs(enc, L, "Wx", grad=True)
         self._dwh = _layer_ptrs(enc, L, "Wh", grad=True)
         self._dbs = _layer_ptrs(enc, L, "bias", grad=True)
-        bounds = sorted({0, self.S} | {min(self.S, max(1, round(f * self.S))) for f in self.FRACTIONS})
-        self.chunks = []  # (s0, s1, t_lo, t_hi, first, last)
+        self.chunks = self.chunk_schedule(T, L, self.FRACTIONS)
+
+    @staticmethod
+    def chunk_schedule(T: int, L: int, fractions) -> list:
+        """[(s0, s1, t_lo, t_hi, first, last)]: tick ranges [s0, s1) of the T + 2(L-1)-tick BPTT wavefront and the
+        time range [t_lo, t_hi) whose gate gradients are complete in EVERY layer once the ticks up to s1 are done
+        (the weight-gradient GEMMs of a chunk read exactly that range).  The ranges tile [0, T) from the top."""
+        S = T + 2 * (L - 1)
+        bounds = sorted({0, S} | {min(S, max(1, round(f * S))) for f in fractions})
+        chunks = []
         t_hi = T
         for s0, s1 in zip(bounds[:-1], bounds[1:]):
             # after launches [0, s1) every layer has finished all t >= T - s1 + 2(L-1)
-            t_lo = 0 if s1 >= self.S else min(T, max(0, T - s1 + 2 * (L - 1)))
-            self.chunks.append((s0, s1, t_lo, t_hi, t_hi == T, s1 >= self.S))
+            t_lo = 0 if s1 >= S else min(T, max(0, T - s1 + 2 * (L - 1)))
+            chunks.append((s0, s1, t_lo, t_hi, t_hi == T, s1 >= S))
             t_hi = t_lo
+        return chunks
 
     def heads(self, phase: int) -> None:
         enc, ws, d = self.enc, self.ws, self.d
