@@ -1,0 +1,154 @@
+"""Model check of the device-side gate protocol (engine._encoder_backward_gated + the decoder's gate + the join): the
+gate operations each stream would enqueue are recorded through a fake `Gates`, then several steps are replayed with
+the device semantics of csrc/misc.hip (a wait passes when flag >= steps * stride + offset and may advance `steps`; a
+stream runs its operations in order).  Checked: no stream ever blocks for good, every ticket counter advances exactly
+once per step, and a chunk's gradient pieces never run before the sweep chunk that completes their time range.
+No GPU needed."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mlx-vae_amd"))
+
+import torch  # noqa: E402
+from arcvae_hip import engine as E  # noqa: E402
+
+
+class _Stream:
+    def __init__(self, name):
+        self.name = name
+
+    def wait_stream(self, other):
+        raise AssertionError("the gated path must not fall back to an event wait here")
+
+
+class _Recorder(E.Gates):
+    """Records gate operations instead of launching them."""
+
+    def __init__(self):  # no device memory
+        self.ops = {}
+        self.cur = None
+
+    def signal(self, w, add=1):
+        self.ops[self.cur].append(("signal", w, add))
+
+    def wait(self, w, steps, stride, offset, advance=False):
+        self.ops[self.cur].append(("wait", w, steps, stride, offset, advance))
+
+    def word(self, i):
+        return ("word", i)
+
+    def note(self, *what):
+        self.ops[self.cur].append(what)
+
+
+class _Plan:
+    def __init__(self, g, T, L, fractions, persistent):
+        self.g, self.persistent = g, persistent
+        self.chunks = E.EncoderBackwardPlan.chunk_schedule(T, L, fractions)
+
+    def heads(self, phase):
+        pass
+
+    def sweep(self, s0, s1, start_signal=None):
+        c = [i for i, ch in enumerate(self.chunks) if ch[0] == s0][0]
+        if start_signal is not None:            # raised by the first launch of the chunk when it starts
+            assert start_signal == ("word", E.Gates.P)
+            self.g.note("signal", E.Gates.P, 1)
+        self.g.note("sweep_done", c)
+
+    def wgrad(self, t_lo, t_hi, first, last, parts=3):
+        c = [i for i, ch in enumerate(self.chunks) if ch[2] == t_lo and ch[3] == t_hi and ch[5] == last][0]
+        self.g.note("wgrad", c, parts)
+
+
+def _record_step(T, L, fractions, persistent, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = _Recorder()
+    main, side, aux = _Stream("main"), _Stream("side"), _Stream("aux")
+    g.ops = {s: [] for s in (main, side, aux)}
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: main)
+    plan = _Plan(g, T, L, fractions, persistent)
+    nc = len(plan.chunks)
+
+    def run(key, fn, stream):
+        g.cur = stream
+        fn()
+
+    def prologue():                              # the forward sweep raises signal #1 when it starts
+        g.note("signal", E.Gates.P, 1)
+
+    def decoder_after_main():                    # StepEngine.enqueue_decoder(gate=(g, nc < 2))
+        g.cur = side
+        g.wait(E.Gates.P, E.Gates.NS, E.Gates.STRIDE, 1, advance=nc < 2)
+        g.signal(E.Gates.D, 1)
+
+    E._encoder_backward_gated(plan, None, aux, side, run, prologue, decoder_after_main, g)
+    g.cur = main
+    if nc >= 2:
+        g.join()                                 # enqueue_finish; single-chunk sweeps join side with an event instead
+    return g.ops, (main, side, aux), nc
+
+
+def _replay(ops, streams, steps):
+    main, side, aux = streams
+    flags = {}
+    pc = {s: 0 for s in streams}
+    prog = {s: ops[s] * steps for s in streams}
+    per = {s: len(ops[s]) for s in streams}
+    sweeps_done = set()                          # (step, chunk)
+    advanced = {}
+    while any(pc[s] < len(prog[s]) for s in streams):
+        moved = False
+        for s in streams:
+            while pc[s] < len(prog[s]):
+                op = prog[s][pc[s]]
+                step = pc[s] // per[s] if per[s] else 0
+                if op[0] == "wait":
+                    _, w, cnt, stride, offset, adv = op
+                    if flags.get(w, 0) < flags.get(cnt, 0) * stride + offset:
+                        break
+                    if adv:
+                        flags[cnt] = flags.get(cnt, 0) + 1
+                        advanced[(cnt, step)] = advanced.get((cnt, step), 0) + 1
+                elif op[0] == "signal":
+                    flags[op[1]] = flags.get(op[1], 0) + op[2]
+                elif op[0] == "sweep_done":
+                    sweeps_done.add((step, op[1]))
+                elif op[0] == "wgrad":
+                    assert (step, op[1]) in sweeps_done, f"{s.name}: gradients of chunk {op[1]} before its sweep (step {step})"
+                pc[s] += 1
+                moved = True
+        assert moved, "deadlock: " + ", ".join(f"{s.name} at {prog[s][pc[s]] if pc[s] < len(prog[s]) else 'end'}" for s in streams)
+    return flags, advanced
+
+
+@pytest.mark.parametrize("env", [{}, {"ARCVAE_TABLE_ON_SIDE": "0"}, {"ARCVAE_WX_ON_SIDE": "1"}, {"ARCVAE_WX_ON_SIDE": "0"}])
+@pytest.mark.parametrize("persistent", [False, True])
+@pytest.mark.parametrize("T,L,fractions", [(128, 2, (0.3, 0.6, 0.85, 1.0)), (128, 2, (0.63, 1.0)), (12, 2, (0.63, 1.0)),
+                                           (40, 4, (0.1, 0.2, 0.3, 0.5, 0.7, 0.9, 1.0)), (9, 1, (0.5, 1.0)), (5, 3, (0.3, 0.6, 0.85, 1.0))])
+def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persistent, env, monkeypatch):
+    ops, streams, nc = _record_step(T, L, fractions, persistent, env, monkeypatch)
+    assert nc >= 2
+    steps = 5
+    flags, advanced = _replay(ops, streams, steps)
+    G = E.Gates
+    assert flags[G.P] == steps * G.STRIDE                      # main: exactly STRIDE signals per step
+    assert flags[G.R] == 2 * steps and flags[G.NM] == steps    # aux and side report once each; main joins once
+    assert flags[G.NS] == steps and flags[G.NA] == steps       # every waiter's ticket counter: once per step
+    assert all(v == 1 for v in advanced.values())
+    # every chunk's gradient pieces are formed exactly once per step, between the streams
+    done = {}
+    for s in streams:
+        for op in ops[s]:
+            if op[0] == "wgrad":
+                c, parts = op[1], op[2]
+                bits = {1: {"wh", "wx"}, 2: {"table"}, 3: {"wh", "wx", "table"}, 4: {"wx"}, 5: {"wh", "wx"}, 6: {"wx", "table"},
+                        7: {"wh", "wx", "table"}, 8: {"wh"}}[parts]
+                for b in bits:
+                    assert (c, b) not in done, (c, b)
+                    done[(c, b)] = s.name
+    assert len(done) == 3 * nc
