@@ -101,10 +101,14 @@ def _replay(ops, streams, steps):
     per = {s: len(ops[s]) for s in streams}
     sweeps_done = set()                          # (step, chunk)
     advanced = {}
+    # adversarial schedule: side and aux run as far as their gates let them, main then executes ONE operation -- a
+    # gradient piece that can start too early will
     while any(pc[s] < len(prog[s]) for s in streams):
         moved = False
-        for s in streams:
-            while pc[s] < len(prog[s]):
+        for s in (side, aux, main):
+            budget = 1 if s is main else 1 << 30
+            while pc[s] < len(prog[s]) and budget > 0:
+                budget -= 1
                 op = prog[s][pc[s]]
                 step = pc[s] // per[s] if per[s] else 0
                 if op[0] == "wait":
