@@ -64,7 +64,7 @@ class _Plan:
         self.g.note("wgrad", c, parts)
 
 
-def _record_step(T, L, fractions, persistent, env, monkeypatch):
+def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = _Recorder()
@@ -86,10 +86,18 @@ def _record_step(T, L, fractions, persistent, env, monkeypatch):
         g.wait(E.Gates.P, E.Gates.NS, E.Gates.STRIDE, 1, advance=nc < 2)
         g.signal(E.Gates.D, 1)
 
-    E._encoder_backward_gated(plan, None, aux, side, run, prologue, decoder_after_main, g)
+    if dp:                                       # dp.py: forward and decoder are enqueued on their own, the backward after them
+        g.cur = main
+        prologue()
+        decoder_after_main()
+        E._encoder_backward_gated(plan, None, aux, side, run, None, None, g)
+        g.cur = main
+        g.wait(E.Gates.D, E.Gates.NM, 1, 1)      # EngineOps._recon_gated: the decoder's gradients are complete
+    else:
+        E._encoder_backward_gated(plan, None, aux, side, run, prologue, decoder_after_main, g)
     g.cur = main
     if nc >= 2:
-        g.join()                                 # enqueue_finish; single-chunk sweeps join side with an event instead
+        g.join()                                 # enqueue_finish / _join_gated
     return g.ops, (main, side, aux), nc
 
 
@@ -134,8 +142,9 @@ def _replay(ops, streams, steps):
 @pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("T,L,fractions", [(128, 2, (0.3, 0.6, 0.85, 1.0)), (128, 2, (0.63, 1.0)), (12, 2, (0.63, 1.0)),
                                            (40, 4, (0.1, 0.2, 0.3, 0.5, 0.7, 0.9, 1.0)), (9, 1, (0.5, 1.0)), (5, 3, (0.3, 0.6, 0.85, 1.0))])
-def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persistent, env, monkeypatch):
-    ops, streams, nc = _record_step(T, L, fractions, persistent, env, monkeypatch)
+@pytest.mark.parametrize("dp", [False, True])
+def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persistent, env, dp, monkeypatch):
+    ops, streams, nc = _record_step(T, L, fractions, persistent, env, monkeypatch, dp)
     assert nc >= 2
     steps = 5
     flags, advanced = _replay(ops, streams, steps)
@@ -143,6 +152,7 @@ def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persis
     assert flags[G.P] == steps * G.STRIDE                      # main: exactly STRIDE signals per step
     assert flags[G.R] == 2 * steps and flags[G.NM] == steps    # aux and side report once each; main joins once
     assert flags[G.NS] == steps and flags[G.NA] == steps       # every waiter's ticket counter: once per step
+    assert flags[G.D] == steps                                 # decoder segments reported (the DP step reduces them early)
     assert all(v == 1 for v in advanced.values())
     # every chunk's gradient pieces are formed exactly once per step, between the streams
     done = {}
