@@ -340,7 +340,7 @@ def main():
                 out["roofline"]["in_step_us_per_launch"] = per
                 out["roofline"]["in_step_frac"] = out["roofline"]["flop_per_launch"] / (per * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
             log("roofline probe done")
-        if args.cpu_steps > 0 and args.config == "default":
+        if args.cpu_steps > 0 and args.config == "default" and world == 1:   # the CPU baseline is an N = 1 figure
             log(f"cpu baseline on {host_cores()} host cores")
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         emit(json.dumps(out))
