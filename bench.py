@@ -9,7 +9,11 @@ A "step" is one pass of the hot path over one minibatch of synthetic SELFIES-sha
 encoder LSTM sweep + heads, dense decoder, ELBO-style loss, hand-written backward, two Adam
 updates (BASELINE.json configs[1]: default AR-CVAE V80 E128 H256 Z128 C1 L2, bs 64, T 128).
 Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, each with its
-own 64-row shard (weak scaling), stats + gradient all-reduce over RCCL.
+own 64-row shard (weak scaling: the headline `value`), stats + gradient all-reduce over RCCL;
+`python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run as
+a child process, before anything touches the GPU) and relays the rank-0 line.  After the weak leg
+every run (N = 1 included) also times the STRONG-scaling leg of BASELINE.json configs[3] --
+global batch 2048 split over the N ranks -- and reports it as the `strong` object.
 
 One JSON line is printed by rank 0 with `roofline` (dominant kernel, live HIP-event timing) and
 `cpu_baseline` (the oracle = CPU restatement of the reference step, timed on this box's host
@@ -20,6 +24,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,6 +51,74 @@ def fwd_flops_per_seq(V, E, H, Z, C, L, T):
     heads = 2 * C * H + 2 * (2 * H) * Z + 2 * (2 * H) * (2 * H) + 2 * (2 * H) * Z
     dec = T * (2 * (E + C) * 4 * H + (L - 1) * 2 * H * 4 * H + 2 * H * V)
     return enc_in + enc_rec + heads + dec
+
+
+def executed_flops_per_step(V, E, H, Z, C, L, T, B):
+    """FLOPs the engine actually EXECUTES per training step (contractions only), next to the reference's algorithmic
+    count: the embedding + layer-0 input projection is a [V,4H] token table (one skinny GEMM per module instead of
+    B*T rows), the decoder is evaluated over B*V (row, token) pairs instead of B*T positions (all four gate columns
+    are computed; the forget gate's are dead but ride in the same GEMM), and the backward mirrors both."""
+    G, R, TB = 4 * H, B * V, T * B
+    enc_f = 2 * V * G * E + (L - 1) * 2 * TB * G * H + L * 2 * (T - 1) * B * G * H            # table0, Wx_l, Wh_l
+    heads_f = B * (2 * C * H + 2 * (2 * H) * Z + 2 * (2 * H) * (2 * H) + 2 * (2 * H) * Z)
+    dec_f = 2 * V * G * E + (L - 1) * 2 * R * G * H + 2 * R * V * H                            # tableD, Wx_l, fc_out
+    enc_b = (L * 2 * (T - 1) * B * G * H + (L - 1) * 2 * TB * G * H                            # dh = dG.Wh, dX = dG.Wx
+             + L * 2 * (T - 1) * B * G * H + (L - 1) * 2 * TB * G * H                          # dWh, dWx_l
+             + 2 * TB * V * G + 2 * (2 * V * G * E))                                           # one-hot GEMM, table finalize
+    heads_b = 2 * heads_f
+    dec_b = (2 * R * V * H * 2 + (L - 1) * 2 * R * G * H * 2 + 2 * (2 * V * G * E))            # dWout+dh, dWx_l+dh_l, table finalize
+    return float(enc_f + heads_f + dec_f + enc_b + heads_b + dec_b)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="default 64 (512 with --config big)")
+    ap.add_argument("--config", choices=["default", "big"], default="default",
+                    help="default = BASELINE.json configs[1]; big = configs[2] (H512 Z256 L4, bs 512: MFMA-bound regime)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", choices=["auto", "graph", "eager", "segments"], default="auto",
+                    help="launch mode: one multi-stream hipGraph, eager launches, or per-stream graph segments")
+    ap.add_argument("--cpu-steps", type=int, default=6, help="oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the dominant-kernel probe (for `rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only`)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel driver (process group + collectives) even at world size 1")
+    ap.add_argument("--strong-global-batch", type=int, default=2048,
+                    help="global batch of the strong-scaling leg (BASELINE.json configs[3]); 0 = skip the leg")
+    ap.add_argument("--strong-steps", type=int, default=30)
+    ap.add_argument("--strong-warmup", type=int, default=6)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="print the torch.distributed.run command --gpus N would start, and exit (no GPU touched)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a CHILD process
+    (python -m torch.distributed.run, one rank per GPU) before this process imports torch or touches the GPU,
+    relay the rank-0 JSON line on stdout and return the child's exit code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child_argv = [a for a in argv if a != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_argv
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log(f"starting {args.gpus} ranks: {' '.join(cmd)}")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    out = proc.stdout.decode(errors="replace")
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    sys.stdout.write((lines[-1] + "\n") if lines else out)
+    sys.stdout.flush()
+    return proc.returncode
 
 
 def synth(rs, B):
@@ -100,24 +174,14 @@ def cpu_baseline(sample_steps: int):
                        f"oracle, {dt:.1f} s; MLX-CPU itself is not installable offline")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch-per-gpu", type=int, default=None, help="default 64 (512 with --config big)")
-    ap.add_argument("--config", choices=["default", "big"], default="default",
-                    help="default = BASELINE.json configs[1]; big = configs[2] (H512 Z256 L4, bs 512: MFMA-bound regime)")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--mode", choices=["auto", "graph", "eager", "segments"], default="auto",
-                    help="launch mode: one multi-stream hipGraph, eager launches, or per-stream graph segments")
-    ap.add_argument("--cpu-steps", type=int, default=6, help="oracle steps for cpu_baseline (0 = skip)")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--roofline-only", action="store_true",
-                    help="run only the dominant-kernel probe (for `rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only`)")
-    ap.add_argument("--force-dp", action="store_true",
-                    help="run the data-parallel driver (process group + collectives) even at world size 1")
-    args = ap.parse_args()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if (args.gpus > 1 and "WORLD_SIZE" not in os.environ) or args.dry_launch:
+        if args.gpus <= 1:
+            print(json.dumps({"launch": None}))
+            return 0
+        return launch_ranks(args, argv)
 
     # Everything except the result line goes to stderr: RCCL prints its version banner on stdout at init.
     sys.stdout.flush()
@@ -168,13 +232,8 @@ def main():
     mode = args.mode
     if mode == "auto":
         mode = "eager" if args.no_graph else "segments"
-    # device-side launch stamps (two 8-byte stores per step launch): the in-step cadence of the dominant kernel is
-    # reported next to its isolated timing (set before the first step: the pointers are baked into the captured graphs)
-    trace_cap = 2 * (T + 2 * L + 4)
-    trace_buf = torch.zeros(2 * trace_cap, dtype=torch.int64, device=dev)
-    _lib.call("arcvae_set_step_trace", _lib.ptr(trace_buf), trace_cap)
 
-    def make_engine():
+    def make_engine(rows, global_rows, trace=False):
         """(Re)initialise the weights and build engine, workspace and DP driver under the current ARCVAE_* knobs."""
         gen = torch.Generator().manual_seed(1234)  # identical initial weights on every rank
         enc.init_mlx_like(H, gen)
@@ -186,44 +245,103 @@ def main():
             st.adam_v.zero_()
         eng_ = E.StepEngine(enc, dec, dims)
         eng_.mode = mode
-        ws_ = eng_.workspace(B, T, train=True)
+        ws_ = eng_.workspace(rows, T, train=True)
+        if trace:
+            # device-side stamps of the sweep ticks / launches (two 8-byte stores each): the in-step cadence of the
+            # dominant kernel is reported next to its isolated timing (before the first step: the pointers are baked
+            # into the captured graphs)
+            eng_.enable_trace(ws_)
         eng_.set_hyper(ws_, **HYPER)
         dp_ = None
         if use_dp:
-            dp_ = DataParallelStep(EngineOps(eng_, ws_, LR, B * world, use_graph=(mode != "eager")))
+            dp_ = DataParallelStep(EngineOps(eng_, ws_, LR, global_rows, use_graph=(mode != "eager")))
         return eng_, ws_, dp_
 
-    eng, ws, dp = make_engine()
+    def make_inputs(rows, total, seed):
+        """device-resident synthetic batches (per-rank shard) and per-step coins (same on every rank, Q5)"""
+        rs = np.random.RandomState(seed + rank)
+        nbuf = 8
+        xs, cs, es = [], [], []
+        for _ in range(nbuf):
+            x, cond = synth(rs, rows)
+            xs.append(torch.tensor(x, device=dev))
+            cs.append(torch.tensor(cond, device=dev))
+            es.append(torch.tensor(rs.standard_normal((rows, Z)).astype(np.float32), device=dev))
+        crs = np.random.RandomState(4242)
+        coins = torch.tensor((crs.rand(total, T) < TF_RATIO).astype(np.uint8), device=dev)
+        return xs, cs, es, coins
 
-    # device-resident synthetic batches (per-rank shard) and per-step coins (same on every rank, Q5)
-    rs = np.random.RandomState(67 + rank)
-    nbuf = 8
-    xs, cs, es = [], [], []
-    for _ in range(nbuf):
-        x, cond = synth(rs, B)
-        xs.append(torch.tensor(x, device=dev))
-        cs.append(torch.tensor(cond, device=dev))
-        es.append(torch.tensor(rs.standard_normal((B, Z)).astype(np.float32), device=dev))
-    crs = np.random.RandomState(4242)
+    def stepper(eng_, ws_, dp_, inputs):
+        xs, cs, es, coins = inputs
+
+        def one_step(i):
+            k = i % len(xs)
+            ws_.x.copy_(xs[k], non_blocking=True)
+            ws_.cond.copy_(cs[k], non_blocking=True)
+            ws_.eps.copy_(es[k], non_blocking=True)
+            ws_.coins.copy_(coins[i], non_blocking=True)
+            if dp_ is None:
+                eng_.run_step(ws_, LR, update=True)
+            else:
+                dp_.step()
+        return one_step
+
+    def all_ranks_max(flag: int) -> int:
+        if world > 1:
+            bt = torch.tensor([flag], device=dev, dtype=torch.int32)
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+            return int(bt.item())
+        return flag
+
+    def timed(one_step, first, count):
+        """EXACTLY `count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        host_enq = 0.0
+        marks = []                                   # ARCVAE_BENCH_INTERVALS=n: an event every n steps (diagnostics)
+        every = int(os.environ.get("ARCVAE_BENCH_INTERVALS", "0"))
+        for i in range(first, first + count):
+            if every and (i - first) % every == 0:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+            h0 = time.perf_counter()
+            one_step(i)
+            host_enq += time.perf_counter() - h0
+        torch.cuda.synchronize()
+        if len(marks) > 1:
+            log("ms/step per interval: " + " ".join(f"{marks[k].elapsed_time(marks[k + 1]) / every:.3f}"
+                                                    for k in range(len(marks) - 1)))
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, host_enq
+
+    def healthy(eng_) -> str:
+        """'' when every device-side gate opened in order and no persistent sweep gave up, on EVERY rank."""
+        bad, why = 0, ""
+        try:
+            eng_.check_gates()
+        except _lib.ArcvaeHipError as e:
+            bad, why = 1, str(e)
+            log(f"rank {rank}: {why}")
+        return (why or "another rank lost its stream order") if all_ranks_max(bad) else ""
+
+    eng, ws, dp = make_engine(B, B * world, trace=True)
     total = args.warmup + args.steps
-    coins = torch.tensor((crs.rand(total, T) < TF_RATIO).astype(np.uint8), device=dev)
-
-    def one_step(i):
-        k = i % nbuf
-        ws.x.copy_(xs[k], non_blocking=True)
-        ws.cond.copy_(cs[k], non_blocking=True)
-        ws.eps.copy_(es[k], non_blocking=True)
-        ws.coins.copy_(coins[i], non_blocking=True)
-        if dp is None:
-            eng.run_step(ws, LR, update=True)
-        else:
-            dp.step()
+    one_step = stepper(eng, ws, dp, make_inputs(B, total, 67))
 
     if args.roofline_only:
         one_step(0)
         torch.cuda.synchronize()
         emit(json.dumps({"roofline": roofline_probe(eng, ws, torch)}))
-        return
+        return 0
     # The host enqueues a step in less than half its device time, but only a few steps ahead: a generational GC pass over
     # the heap torch leaves behind (~10 ms) lands on the device timeline as a stall.  The loop below allocates nothing
     # that needs cycle collection.  (ARCVAE_BENCH_GC=1 leaves the collector on.)
@@ -241,18 +359,9 @@ def main():
         # Health check before anything is timed: a device-side gate or a persistent sweep that gave up waiting (a
         # device whose queues / CUs are not laid out as probed) must not produce a number.  All ranks agree, then
         # everybody drops one level: gates -> event waits, persistent sweeps -> per-step launches.
-        bad = 0
-        try:
-            eng.check_gates()
-        except _lib.ArcvaeHipError as e:
-            log(f"rank {rank}: {e}")
-            bad = 1
+        bad = 1 if healthy(eng) else 0
         if attempt < int(os.environ.get("ARCVAE_BENCH_TEST_FALLBACK", "0")):
             bad = 1                                  # rehearsal of the fallback path (tests / tools only)
-        if world > 1:
-            bt = torch.tensor([bad], device=dev, dtype=torch.int32)
-            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-            bad = int(bt.item())
         if not bad:
             break
         if attempt == 0:
@@ -265,59 +374,29 @@ def main():
             raise SystemExit("bench.py: the step does not run cleanly on this device even without gates and "
                              "persistent sweeps")
         log(f"rank {rank}: falling back to {fallback}")
-        eng, ws, dp = make_engine()
+        eng, ws, dp = make_engine(B, B * world, trace=True)
+        one_step = stepper(eng, ws, dp, make_inputs(B, total, 67))
     log("timing")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    host_enq = 0.0
-    marks = []                                       # ARCVAE_BENCH_INTERVALS=n: an event every n steps (diagnostics)
-    every = int(os.environ.get("ARCVAE_BENCH_INTERVALS", "0"))
-    for i in range(args.warmup, total):
-        if every and (i - args.warmup) % every == 0:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            marks.append(ev)
-        h0 = time.perf_counter()
-        one_step(i)
-        host_enq += time.perf_counter() - h0
-    torch.cuda.synchronize()
-    if len(marks) > 1:
-        log("ms/step per interval: " + " ".join(f"{marks[k].elapsed_time(marks[k + 1]) / every:.3f}"
-                                                for k in range(len(marks) - 1)))
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, host_enq = timed(one_step, args.warmup, args.steps)
     scal = ws.scalars.cpu().numpy()
     # a device-side gate or a persistent sweep that gave up waiting would mean the streams lost their order: no number
-    # then -- and every rank leaves together (a lone exit would park the others in the barrier below)
-    bad, why = 0, ""
-    try:
-        eng.check_gates()
-    except _lib.ArcvaeHipError as e:
-        bad, why = 1, str(e)
-        log(f"rank {rank}: {why}")
-    if world > 1:
-        bt = torch.tensor([bad], device=dev, dtype=torch.int32)
-        dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-        bad = int(bt.item())
-    if bad:
+    # then -- and every rank leaves together (a lone exit would park the others in a barrier)
+    why = healthy(eng)
+    if why:
         if use_dp:
             dist.destroy_process_group()
         raise SystemExit("bench.py: stream ordering was lost during the timed steps " + why)
 
+    out = None
     if rank == 0:
         ms = 1e3 * dt / args.steps
         seqs = B * world * args.steps / dt
         f_seq = 3 * fwd_flops_per_seq(V, EMB, H, Z, C, L, T)
+        f_exec = executed_flops_per_step(V, EMB, H, Z, C, L, T, B)
         out = {
             "metric": "SELFIES sequences/sec (whole node), AR-CVAE training step",
-            "value": seqs, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": seqs, "unit": "sequences/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if use_dp else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl_name}, bs {B}/GPU, T 128, tf 0.9, "
@@ -326,27 +405,72 @@ def main():
                        "launch_mode": mode, "fallback": fallback},
             "elbo": {"total": float(scal[0]), "recon": float(scal[1]), "kl": float(scal[2]),
                      "mutual_info": float(scal[7])},
+            # algorithmic = the REFERENCE's FLOPs for this step (decoder over B*T positions, embedding
+            # as per-token GEMM rows) / time; executed = what the engine's kernels really contract (token tables,
+            # decoder over B*V pairs): the hardware-use figure
             "step_tflops_algorithmic": seqs * f_seq / 1e12,
-            "step_frac_of_f32_mfma_peak": seqs * f_seq / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+            "step_algorithmic_frac_of_f32_mfma_peak": seqs * f_seq / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+            "step_tflops_executed": f_exec / (dt / args.steps) / 1e12,
+            "step_executed_frac_of_f32_mfma_peak": f_exec / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
         }
         log(f"timed: {ms:.3f} ms/step, {seqs:.0f} seq/s (host enqueue {1e3 * host_enq / args.steps:.3f} ms/step)")
-        if not args.no_roofline:
-            tr = trace_buf.cpu().numpy().reshape(trace_cap, 2).astype(np.float64) / 100.0  # us, last timed step
-            nb = T + 2 * (L - 1)
-            bw = tr[trace_cap // 2: trace_cap // 2 + nb]
-            out["roofline"] = roofline_probe(eng, ws, torch)
-            if nb > 1 and bw[-1, 0] > bw[0, 0]:
-                per = float((bw[-1, 0] - bw[0, 0]) / (nb - 1))
-                out["roofline"]["in_step_us_per_launch"] = per
-                out["roofline"]["in_step_frac"] = out["roofline"]["flop_per_launch"] / (per * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
-            log("roofline probe done")
+    if rank == 0 and not args.no_roofline:
+        nb = T + 2 * (L - 1)
+        bw = ws.trace_bwd.cpu().numpy().reshape(-1, 2).astype(np.float64)[:nb] / 100.0   # us, last timed step
+        out["roofline"] = roofline_probe(eng, ws, torch)
+        if nb > 1 and bw[-1, 0] > bw[0, 0]:
+            per = float((bw[-1, 0] - bw[0, 0]) / (nb - 1))
+            out["roofline"]["in_step_us_per_launch"] = per
+            out["roofline"]["in_step_frac"] = out["roofline"]["flop_per_launch"] / (per * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+        log("roofline probe done")
+
+    # ---- strong-scaling leg (BASELINE.json configs[3]: global batch 2048 over the N ranks; N = 1 included so that the
+    # 1 -> N ratio comes from one tool).  Its own engine / workspace, timed after the weak leg.
+    G2 = args.strong_global_batch
+    if G2 > 0 and args.config == "default" and not args.batch_per_gpu:
+        strong = None
+        if G2 % world != 0:
+            strong = {"global_batch": G2, "skipped": f"{G2} rows do not split evenly over {world} ranks"}
+        else:
+            rows = G2 // world
+            del one_step, dp
+            eng = ws = None
+            torch.cuda.empty_cache()
+            eng2, ws2, dp2 = make_engine(rows, G2)
+            stotal = args.strong_warmup + args.strong_steps
+            step2 = stepper(eng2, ws2, dp2, make_inputs(rows, stotal, 167))
+            for i in range(args.strong_warmup):
+                step2(i)
+            torch.cuda.synchronize()
+            why = healthy(eng2)
+            if not why:
+                dt2, _ = timed(step2, args.strong_warmup, args.strong_steps)
+                why = healthy(eng2)
+            if why:
+                strong = {"global_batch": G2, "rows_per_gpu": rows, "skipped": why}
+            else:
+                sc2 = ws2.scalars.cpu().numpy()
+                strong = {"global_batch": G2, "rows_per_gpu": rows, "n_gpus": world, "steps": args.strong_steps,
+                          "warmup": args.strong_warmup, "ms_per_step": 1e3 * dt2 / args.strong_steps,
+                          "value": G2 * args.strong_steps / dt2, "unit": "sequences/s", "scaling": "strong",
+                          "elbo": {"total": float(sc2[0]), "recon": float(sc2[1]), "kl": float(sc2[2])},
+                          "bptt_kernel": ("lstm_bwd_persist_rs_kernel" if E.bptt_reduce_scatter_ok(ws2, dims)
+                                          else "per-step launches (lstm_bwd_step*/tile kernels)")}
+                log(f"strong leg: global batch {G2} = {rows} rows/GPU x {world}: {strong['ms_per_step']:.3f} ms/step, "
+                    f"{strong['value']:.0f} seq/s")
+        if rank == 0:
+            out["strong"] = strong
+    if rank == 0:
         if args.cpu_steps > 0 and args.config == "default" and world == 1:   # the CPU baseline is an N = 1 figure
             log(f"cpu baseline on {host_cores()} host cores")
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+            out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]   # (vs_baseline stays null: BASELINE.md
+            # holds no published number for this metric; the CPU figure is this repo's restatement, kind "port")
         emit(json.dumps(out))
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 def roofline_probe(eng, ws, torch):
@@ -376,11 +500,11 @@ def roofline_probe(eng, ws, torch):
         if persistent:   # the whole sweep as one launch of lstm_bwd_persist_rs_kernel: `launches` ticks
             E.call("arcvae_enc_lstm_backward_persistent_rs", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb),
                    2 * d.H, E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.ppart), E.ptr(ws.psync), None, B, Tn,
-                   d.H, d.L, 0, launches, E.stream_ptr())
+                   d.H, d.L, 0, launches, 0, None, E.stream_ptr())
             return
         E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * d.H,
                E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, Tn, d.H, d.L, 0, launches,
-               1, None, E.stream_ptr())
+               1, None, None, E.stream_ptr())
 
     sweep()
     torch.cuda.synchronize()
@@ -410,31 +534,48 @@ def roofline_probe(eng, ws, torch):
     flops_total = 2.0 * B * 4 * d.H * d.H * (d.L * (Tn - 1) + (d.L - 1) * Tn)
     ach = flops_total / launches / (us * 1e-6) / 1e12
     kernel = "lstm_bwd_persist_rs_kernel" if persistent else "lstm_bwd_step_kernel"
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc):
+    # traffic: fabric-side bytes per tick / launch from the newest committed rocprofv3 --pmc summary (separate passes,
+    # tools/pmc.sh; 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction) -- a profile figure, named by its file, not
+    # measured in this run.  tick_model: where a tick's time goes (tools/probe_persist.hip on the same chip).
+    def newest(pattern):
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return files[-1] if files else None
+    traffic, traffic_source = None, None
+    pmc = newest("r*_pmc_summary.json")
+    if pmc:
         try:
             ent = json.load(open(pmc)).get(kernel, {})
             traffic = ent.get("bytes_per_tick", ent.get("bytes_per_launch"))
+            traffic_source = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc, separate passes; not measured in this run)"
         except Exception:
             traffic = None
+    tick_model = None
+    tm = newest("r*_tick_model.json")
+    if tm and persistent:
+        try:
+            tick_model = json.load(open(tm))
+            tick_model["source"] = "profiles/" + os.path.basename(tm)
+        except Exception:
+            tick_model = None
     if persistent:
         note = ("dominant kernel: the persistent BPTT sweep (lstm_bwd_persist_rs_kernel, one launch per chunk; DESIGN.md "
                 "section 6b); a 'launch' here is one TICK of it (same 2L-1 contractions as a launch of the per-step "
                 "kernel it replaced).  achieved = isolated sweep as ONE launch (HIP events on its stream) / ticks; "
                 "in_step_* = tick cadence inside the last timed step (device-side stamps, weight-gradient GEMMs beside it). "
-                "f32-input MFMA peak (exact-f32 path); a tick is bound by the per-XCD barrier and one L2 round trip of the "
-                "reduce-scatter, not by MFMA; traffic = (2*FETCH_SIZE + WRITE_SIZE) / ticks from profiles/r01_pmc_summary.json")
+                "`bound` names the section-8(d) denominator (f32-input MFMA peak, exact-f32 path); the LIMITER is the "
+                "tick latency of a 259-tick dependent chain (exchange through the XCD's L2, block barriers, epilogue), "
+                "not MFMA issue or HBM bytes: see tick_model")
     else:
         note = ("achieved = isolated BPTT sweep (HIP events on its stream); in_step_* = start-to-start cadence of the "
                 "same launches inside the last timed step (device-side stamps, side-stream GEMMs running beside "
-                "them).  f32-input MFMA peak (exact-f32 path); the launch is bound by the dependent-chain seam "
-                "(1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6; traffic = "
-                "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_summary.json (separate --pmc passes)")
-    return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "them).  `bound` names the section-8(d) denominator (f32-input MFMA peak); the LIMITER is the "
+                "dependent-chain seam (1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6")
+    return {"bound": "mfma", "limiter": "latency", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
             "us_per_launch": us, "launches_per_sweep": launches,
-            "flop_per_launch": flops_total / launches, "note": note}
+            "flop_per_launch": flops_total / launches, "tick_model": tick_model, "note": note}
+
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -11,7 +11,9 @@
  *   - no allocation, no ownership transfer: every buffer is caller-owned DEVICE memory,
  *     contiguous row-major float32 unless stated, parameter tensors 16-byte aligned;
  *   - asynchronous on `stream` (a hipStream_t passed as void*); safe under hipGraph capture
- *     (no sync, no malloc); re-entrant (no global mutable state);
+ *     (no sync, no malloc); re-entrant: no global mutable host state -- chunk indices, trace buffers and
+ *     sync scratch are arguments; the only process-wide values are ARCVAE_* tuning knobs read once
+ *     from the environment (immutable afterwards);
  *   - `const float* const*` arguments are HOST arrays of device pointers (one per LSTM layer);
  *   - gradients are accumulated ("+="): zero the flat gradient buffer once per step;
  *   - float32 arithmetic throughout (the reference's dtype), contractions on the exact-f32
@@ -66,7 +68,8 @@ int arcvae_transpose_tokens(const int32_t* src_bt, int32_t* dst_tb, int B, int T
 int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                             const float* const* Wh, const float* const* bias, float* hseq, float* hseq_t,
                             float* cseq, float* gseq, float* wt, float* wT_bwd /* optional */, int B, int T, int V,
-                            int H, int L, arcvae_stream_t stream);
+                            int H, int L, unsigned long long* trace /* optional diagnostic: {start,end} 100 MHz stamps
+                            of launch s at trace[2s..2s+1], 2*(T+L-1) u64 */, arcvae_stream_t stream);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
  * position read by models/encoder.py:106.  dG out [L,T,B,4H] (may alias gseq: in-place); dG_t ws [L,RS,B*4H]; dcs, dxs
@@ -75,24 +78,30 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
                              const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dG_t,
                              float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,
                              int s_end, int retile, unsigned* start_signal /* optional: += 1 when the first launch of
-                             this call starts (all earlier work of the stream is complete) */, arcvae_stream_t stream);
+                             this call starts (all earlier work of the stream is complete) */,
+                             unsigned long long* trace /* optional diagnostic: stamps of launch s at trace[2s..2s+1],
+                             2*(T+2(L-1)) u64 */, arcvae_stream_t stream);
 /* The same forward sweep as ONE persistent launch for the latency regime (H = 128, 256 or 384, L <= 4, B <= 256, weight
  * slices within LDS; arcvae_enc_lstm_persistent_ok says whether a shape qualifies): batch rows partitioned over the 8
  * XCDs, weights stationary in LDS, one flag-line barrier per XCD and tick.  No k-chunk-major h
  * copy is written.  sync_ws: 512 u32 of scratch; sync_ws[500] != 0 afterwards = a block gave up waiting (sticky).
  * start_signal (optional): += 1 when the sweep starts.  The BPTT counterpart covers ticks [s_begin, s_end) of
  * arcvae_enc_lstm_backward's schedule per launch (L <= 2, ceil(B/8) * H/32 <= 64); a sweep uses it for all its
- * chunks or for none (no k-chunk-major dG copy is written). */
+ * chunks or for none (no k-chunk-major dG copy is written).  chunk_index: 0 for the launch with s_begin == 0 (it
+ * re-arms sync_ws), then 1, 2, .. (< 8) for the following chunk launches of the same sweep: every chunk launch draws
+ * its block roles from its own counters.  trace (optional diagnostic): per-tick {start,end} stamps of one block at
+ * trace[2s..2s+1] (forward: s < T+L-1; BPTT: the sweep's global tick index s < T+2(L-1)). */
 int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
                                        float* gseq, float* wt, float* wT_bwd, unsigned* sync_ws, unsigned* start_signal,
-                                       int B, int T, int V, int H, int L, arcvae_stream_t stream);
+                                       int B, int T, int V, int H, int L, unsigned long long* trace,
+                                       arcvae_stream_t stream);
 int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, const float* dh_top, int ld_dh_top,
                                         float* dG, float* dcs, float* dxs, const float* wT, unsigned* sync_ws,
                                         unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
-                                        arcvae_stream_t stream);
+                                        int chunk_index, unsigned long long* trace, arcvae_stream_t stream);
 /* Reduce-scatter form of the persistent BPTT sweep (H = 256, L <= 2, B <= 64): a CU keeps the gate gradients of its own
  * 32 gate columns on chip, multiplies them with its 32 rows of the row-major Wh / Wx, and the partial sums are
  * reduce-scattered through the XCD's L2 (part_ws: 2*(2L-1)*8*32*32*64 floats).  Otherwise as
@@ -101,7 +110,8 @@ int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
                                            const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
                                            float* dxs, float* part_ws, unsigned* sync_ws, unsigned* start_signal, int B,
-                                           int T, int H, int L, int s_begin, int s_end, arcvae_stream_t stream);
+                                           int T, int H, int L, int s_begin, int s_end, int chunk_index,
+                                           unsigned long long* trace, arcvae_stream_t stream);
 /* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,
@@ -135,11 +145,15 @@ int arcvae_latent_loss(const float* stats, const float* hyper, const float* mu, 
                        arcvae_stream_t stream);
 /* recon = stats[2Z+3]/(B_global*T) and total, once the decoder's CE row sums are in stats (latent_loss may run
  * before that: the encoder's backward does not depend on the reconstruction term, Q2). */
-int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, arcvae_stream_t stream);
+/* guard_a / guard_b (optional, here and in arcvae_recon_finalize): device error words as in arcvae_adam_update; when
+ * either is non-zero the nine loss scalars are set to NaN and scalars[15] = 1 (else scalars[15] = 0), so the host's
+ * per-batch read of the loss (trainer.py:366) also carries the "stream order was lost" status. */
+int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, const unsigned* guard_a,
+                         const unsigned* guard_b, arcvae_stream_t stream);
 /* arcvae_stats_set_recon + arcvae_loss_finalize in one launch (single-process step: losses/recon.py:59-60 mean over
  * B*T and complete_vae_loss.py:76-82 total). */
 int arcvae_recon_finalize(const float* rowloss, int B, float* stats, float* scalars, int Z, int T,
-                          arcvae_stream_t stream);
+                          const unsigned* guard_a, const unsigned* guard_b, arcvae_stream_t stream);
 int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* Wlh, const float* Wlv,
                               const float* comb, const float* lh, const float* dmu_raw, const float* dlv_raw,
                               float* dlh, float* dcomb, float* dWc, float* dbc, float* dWmu, float* dbmu,
@@ -190,9 +204,13 @@ int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const fl
 
 /* ---- optimizer ------------------------------------------------------------------------------------
  * trainer.py:75-76,320,324: MLX optim.Adam, NO bias correction (Q7):
- * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p = p - lr m / (sqrt(v) + eps), over a flat buffer. */
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p = p - lr m / (sqrt(v) + eps), over a flat buffer.
+ * guard_a / guard_b (optional): device error words (engine: the gates' ERR word and the persistent sweeps'
+ * sync_ws[500]); when either is non-zero at execution time the update is skipped -- gradients formed after a lost
+ * stream order must not reach the weights. */
 int arcvae_adam_update(float* params, const float* grads, float* m, float* v, long n, double lr,
-                       double beta1, double beta2, double eps, arcvae_stream_t stream);
+                       double beta1, double beta2, double eps, const unsigned* guard_a, const unsigned* guard_b,
+                       arcvae_stream_t stream);
 
 /* ---- small helpers ---------------------------------------------------------------------------------- */
 int arcvae_colsum_accum(const float* X, int rows, int cols, int ld, float* out, float scale,
@@ -216,10 +234,6 @@ int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw, const floa
 int arcvae_gate_wait(const unsigned* flag, unsigned* steps, unsigned stride, unsigned offset, int advance,
                      unsigned max_polls, unsigned* err, arcvae_stream_t stream);
 int arcvae_gate_set(unsigned* flag, unsigned value, int add, arcvae_stream_t stream);
-/* Diagnostic (tools/step_trace.py; no reference counterpart): device-side {start,end} stamps, 100 MHz ticks, of the
- * LSTM step launches recorded after this call.  buf: 2*cap u64 (forward launch s -> slot s, BPTT launch s -> slot
- * cap/2 + s); buf = NULL switches tracing off (default). */
-int arcvae_set_step_trace(unsigned long long* buf, int cap);
 int arcvae_tile_weights(const float* const* src, float* const* dst, const int* cols, const int* mode, int n, int H,
                         arcvae_stream_t stream);
 

@@ -32,20 +32,20 @@ SIGNATURES = {
     "arcvae_abi_version": [_ip],
     "arcvae_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp],
     "arcvae_transpose_tokens": [_vp, _vp, _i, _i, _vp],
-    "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_persistent_ok": [_i, _i, _i, _i],
-    "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_persistent_ok": [_i, _i, _i, _i],
-    "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_rs_ok": [_i, _i, _i, _i],
-    "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _vp],
     "arcvae_stats_set_recon": [_vp, _i, _vp, _i, _vp],
     "arcvae_latent_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
-    "arcvae_loss_finalize": [_vp, _vp, _i, _i, _vp],
-    "arcvae_recon_finalize": [_vp, _i, _vp, _vp, _i, _i, _vp],
+    "arcvae_loss_finalize": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "arcvae_recon_finalize": [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_heads_backward": [_vp] * 18 + [_i, _i, _i, _i, _i, _vp],
     "arcvae_dec_forward_dense": [_vp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _i, _i, _i, _f, _vp],
@@ -59,13 +59,12 @@ SIGNATURES = {
     "arcvae_latent_stats": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "arcvae_ce_rows": [_vp, _vp, _vp, _l, _i, _vp],
     "arcvae_sum": [_vp, _l, _vp, _f, _vp],
-    "arcvae_adam_update": [_vp, _vp, _vp, _vp, _l, _d, _d, _d, _d, _vp],
+    "arcvae_adam_update": [_vp, _vp, _vp, _vp, _l, _d, _d, _d, _d, _vp, _vp, _vp],
     "arcvae_colsum_accum": [_vp, _i, _i, _i, _vp, _f, _vp],
     "arcvae_segsum_rows_accum": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "arcvae_transpose_batched": [_pp, _pp, _ip, _ip, _i, _vp],
     "arcvae_scale_inplace": [_vp, _l, _f, _vp],
     "arcvae_zero": [_vp, _i, _i, _i, _vp],
-    "arcvae_set_step_trace": [_vp, _i],
     "arcvae_table_finalize": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "arcvae_gate_wait": [_vp, _vp, C.c_uint, C.c_uint, _i, C.c_uint, _vp, _vp],
     "arcvae_gate_set": [_vp, C.c_uint, _i, _vp],

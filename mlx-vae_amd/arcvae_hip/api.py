@@ -35,9 +35,11 @@ def draw_eps(B: int, Z: int, device, generator: Optional[torch.Generator] = None
     return torch.randn(B, Z, device=device, dtype=torch.float32, generator=generator)
 
 
-def _as_dict(eng: StepEngine, ws, clone: bool) -> Dict[str, torch.Tensor]:
+def _as_dict(eng: StepEngine, ws, clone: bool, status: bool = False) -> Dict[str, torch.Tensor]:
     sc = ws.scalars.clone()  # 16 floats: always detach from the static buffer the next call overwrites
     out = {k: sc[i] for i, k in enumerate(SCALAR_KEYS)}
+    if status:   # [total_loss, step status]: ONE D2H read gives the trainer the loss and "stream order was lost"
+        out["loss_and_status"] = sc[::15]     # elements 0 and 15 of the 16
     for k in ("mu", "logvar", "z"):
         t = getattr(ws, k)
         out[k] = t.clone() if clone else t
@@ -68,4 +70,4 @@ def value_and_grad(encoder, decoder, x, conditions, eps=None, coins=None, teache
         eps = draw_eps(B, encoder.latent_dim, encoder.store.device)
     eng.train_step(x, conditions, eps, coins, lr=lr if lr is not None else 0.0, update=lr is not None, **hyper)
     ws = eng.workspace(B, T, train=True)
-    return _as_dict(eng, ws, clone=False), (encoder.gradients(), decoder.gradients())
+    return _as_dict(eng, ws, clone=False, status=True), (encoder.gradients(), decoder.gradients())

@@ -183,9 +183,10 @@ class EngineOps:
 
         def fn():
             ws.stats[2 * Z + 3:2 * Z + 4].copy_(self.bucket_recon)   # GLOBAL CE sum
-            call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), Z, ws.T, stream_ptr())
-            adam_update(eng.dec, self.lr)
-            adam_update(eng.enc, self.lr)
+            ga, gb = eng.guards(ws)
+            call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), Z, ws.T, ga, gb, stream_ptr())
+            adam_update(eng.dec, self.lr, guards=(ga, gb))
+            adam_update(eng.enc, self.lr, guards=(ga, gb))
         self.run("dp_finish", fn, torch.cuda.current_stream())
 
     # ---- StepOps ----------------------------------------------------------------------------------------

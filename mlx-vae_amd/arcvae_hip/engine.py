@@ -92,6 +92,9 @@ class Workspace:
         self.z = torch.empty(B, Z, **f32)
         self.stats = torch.zeros(2 * Z + 4, **f32)
         self.psync = torch.zeros(512, **i32)     # scratch of the persistent sweeps (flags, role counters; [500] = error)
+        # optional diagnostic stamps of the sweep launches / ticks (StepEngine.enable_trace), passed per call
+        self.trace_fwd: Optional[torch.Tensor] = None
+        self.trace_bwd: Optional[torch.Tensor] = None
         self.scalars = torch.zeros(16, **f32)
         # decoder forward (dense over B*V rows)
         self.tableD = torch.empty(V, G, **f32)
@@ -167,12 +170,12 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
     if persistent_forward_ok(ws, d):
         call("arcvae_enc_lstm_forward_persistent", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq),
              ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, ptr(ws.psync),
-             start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L, s)
+             start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L, ptr(ws.trace_fwd), s)
     else:
         if start_signal is not None:
             call("arcvae_gate_set", start_signal, 1, 1, s)
         call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
-             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, s)
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, ptr(ws.trace_fwd), s)
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
          ptr(enc.p("condition_fc.bias")), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
@@ -378,7 +381,9 @@ class EncoderBackwardPlan:
              ptr(enc.g("fc_logvar_hidden.weight")), ptr(enc.g("fc_logvar_hidden.bias")),
              ptr(enc.g("fc_logvar.weight")), ptr(enc.g("fc_logvar.bias")), ws.B, d.H, d.Z, d.C, phase, stream_ptr())
 
-    def sweep(self, s0: int, s1: int, start_signal: Optional[C.c_void_p] = None) -> None:
+    def sweep(self, s0: int, s1: int, start_signal: Optional[C.c_void_p] = None, chunk_index: int = 0) -> None:
+        """Ticks [s0, s1) of the BPTT wavefront; chunk_index = position of this call among the sweep's chunk calls
+        (the persistent kernels draw their block roles from per-chunk counters)."""
         # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
         sig = start_signal if start_signal is not None else C.c_void_p(0)
@@ -387,17 +392,18 @@ class EncoderBackwardPlan:
             # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
             call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
                  ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), ptr(ws.psync), sig,
-                 ws.B, ws.T, d.H, d.L, s0, s1, stream_ptr())
+                 ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, ptr(ws.trace_bwd), stream_ptr())
             return
         if _lib.load().arcvae_enc_lstm_bwd_persistent_ok(ws.B, ws.T, d.H, d.L) == 1:
             # latency regime: one persistent launch per chunk (csrc/lstm.hip: lstm_bwd_persist_kernel)
             call("arcvae_enc_lstm_backward_persistent", ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG),
-                 ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ptr(ws.psync), sig, ws.B, ws.T, d.H, d.L, s0, s1, stream_ptr())
+                 ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ptr(ws.psync), sig, ws.B, ws.T, d.H, d.L, s0, s1, chunk_index,
+                 ptr(ws.trace_bwd), stream_ptr())
             return
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
              2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
              0,  # retile = 0: the forward of this step already wrote the BPTT weight layouts
-             start_signal if start_signal is not None else C.c_void_p(0), stream_ptr())
+             start_signal if start_signal is not None else C.c_void_p(0), ptr(ws.trace_bwd), stream_ptr())
 
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3) -> None:
         enc, ws, d = self.enc, self.ws, self.d
@@ -437,7 +443,7 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
                 if prologue:
                     prologue()
                 plan.heads(1)
-            plan.sweep(s0, s1)
+            plan.sweep(s0, s1, None, c)
 
         split_tail = last and aux2 is not None  # the last chunk is the exposed tail: run its two halves side by side
 
@@ -493,7 +499,7 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             prologue()
         plan.heads(1)
         for c, (s0, s1, _t_lo, _t_hi, _first, _last) in enumerate(plan.chunks):
-            plan.sweep(s0, s1, g.word(g.P) if c > 0 else None)
+            plan.sweep(s0, s1, g.word(g.P) if c > 0 else None, c)
         g.signal(g.P, g.STRIDE - nc)
 
     run("main", main_seg, main)
@@ -530,10 +536,15 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     # ~2 us; an event wait on two other queues cost ~20 us of the exposed tail).
 
 
-def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
-    """trainer.py:320,324 -> MLX optim.Adam (no bias correction, Q7) over the module's flat buffer."""
+NO_GUARDS = (C.c_void_p(0), C.c_void_p(0))
+
+
+def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,
+                guards=NO_GUARDS) -> None:
+    """trainer.py:320,324 -> MLX optim.Adam (no bias correction, Q7) over the module's flat buffer.
+    guards: two device error words (StepEngine.guards); the kernel skips the update when either is non-zero."""
     call("arcvae_adam_update", ptr(store.flat), ptr(store.grad), ptr(store.adam_m), ptr(store.adam_v),
-         C.c_long(store.numel_padded), float(lr), float(b1), float(b2), float(eps), stream_ptr())
+         C.c_long(store.numel_padded), float(lr), float(b1), float(b2), float(eps), guards[0], guards[1], stream_ptr())
 
 
 # --------------------------------------------------------------------------------------------
@@ -596,6 +607,21 @@ class StepEngine:
                 print("[arcvae_hip] no three streams on distinct hardware queues found: keeping event waits")
             self._gating = {key: ok}  # side/aux may have changed: other main streams are re-probed
         return self._gating[key]
+
+    def guards(self, ws: Workspace):
+        """The two device error words of a step: the gates' ERR counter and the persistent sweeps' sticky error word.
+        The loss-finalize and Adam kernels read them ON THE DEVICE: a step whose stream order was lost gets NaN loss
+        scalars (+ scalars[15] = 1) and NO parameter update -- the weights survive until the host notices
+        (`step_status`, read by the trainer with its per-batch loss; `check_gates`)."""
+        ga = self.gates.word(Gates.ERR) if self.gates is not None else C.c_void_p(0)
+        return ga, C.c_void_p(ws.psync.data_ptr() + 4 * 500)
+
+    def enable_trace(self, ws: Workspace) -> None:
+        """Diagnostic: allocate the per-launch / per-tick stamp buffers of the two sweeps ({start, end} in 100 MHz
+        ticks at [2s], [2s+1]); must precede the first (captured) step of this workspace."""
+        L = self.d.L
+        ws.trace_fwd = torch.zeros(2 * (ws.T + L + 1), dtype=torch.int64, device=self.device)
+        ws.trace_bwd = torch.zeros(2 * (ws.T + 2 * L + 2), dtype=torch.int64, device=self.device)
 
     def check_gates(self) -> None:
         """Raise if a gate ever gave up waiting (results after that point are not ordered).  Host sync."""
@@ -683,7 +709,7 @@ class StepEngine:
         def dec_bwd():
             decoder_backward(self.dec, ws, d, 1.0 / (global_rows * ws.T))
             if adam_lr is not None:
-                adam_update(self.dec, adam_lr)
+                adam_update(self.dec, adam_lr, guards=self.guards(ws))
             if gate is not None:
                 # decoder gradients and CE row sums of this step are complete (read by the data-parallel step, which
                 # reduces them early; raised in every gated step so that D stays in lockstep with main's step count)
@@ -747,15 +773,16 @@ class StepEngine:
         def fin():
             if gates is not None:
                 gates.join()
+            ga, gb = self.guards(ws)
             if with_recon:   # CE sum + recon/total scalars in one launch
                 call("arcvae_recon_finalize", ptr(ws.rowloss), ws.B, ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T,
-                     stream_ptr())
+                     ga, gb, stream_ptr())
             else:
-                call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
+                call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, ga, gb, stream_ptr())
             if update:
                 if dec_adam:
-                    adam_update(self.dec, lr)
-                adam_update(self.enc, lr)
+                    adam_update(self.dec, lr, guards=(ga, gb))
+                adam_update(self.enc, lr, guards=(ga, gb))
 
         run(("finish" if update else "finish_noupdate") + ("_r" if with_recon else ""), fin, main)
 
@@ -805,7 +832,8 @@ class StepEngine:
         self.enqueue_decoder(ws, B, backward=False, wait_current=False)
         latent_loss(ws, self.d, float(self.hyper_host["free_bits"]), False)
         self.enqueue_recon(ws)
-        call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
+        ga, gb = self.guards(ws)
+        call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T, ga, gb, stream_ptr())
         torch.cuda.current_stream().wait_stream(self.side)
         return self._results(ws)
 
@@ -840,6 +868,7 @@ class StepEngine:
     def _results(self, ws: Workspace) -> Dict[str, torch.Tensor]:
         out = {k: ws.scalars[i] for i, k in enumerate(SCALAR_KEYS)}
         out["mu"], out["logvar"], out["z"] = ws.mu, ws.logvar, ws.z
+        out["step_status"] = ws.scalars[15]   # 1.0: a gate expired / a persistent sweep gave up (values NaN, no update)
         return out
 
     def gather_logits(self, ws: Workspace) -> torch.Tensor:

@@ -251,11 +251,25 @@ extern "C" int arcvae_latent_loss(const float* stats, const float* hyper, const 
 // arcvae_latent_loss may therefore run BEFORE the decoder has finished: nothing on the encoder's backward
 // path depends on the reconstruction term (Q2).
 namespace {
-__global__ void loss_finalize_kernel(const float* __restrict__ stats, float* scalars, int Z, int T) {
+// guard words (optional): an expired gate / a persistent sweep that gave up.  Non-zero -> this step's numbers are
+// not ordered results: the nine loss scalars become NaN and scalars[15] = 1 (the trainer reads both in its per-batch
+// D2H copy and raises at that batch; arcvae_adam_update skips the update on the same words).
+__device__ __forceinline__ bool step_guard_tripped(const unsigned* ga, const unsigned* gb) {
+    return (ga && __hip_atomic_load(ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
+           (gb && __hip_atomic_load(gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+}
+__device__ __forceinline__ void poison_scalars(float* scalars) {
+    for (int i = 0; i < 9; ++i) scalars[i] = __builtin_nanf("");
+    scalars[15] = 1.0f;
+}
+__global__ void loss_finalize_kernel(const float* __restrict__ stats, float* scalars, int Z, int T,
+                                     const unsigned* ga, const unsigned* gb) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float recon = stats[2 * Z + 3] / (stats[2 * Z + 2] * (float)T);
         scalars[1] = recon;
         scalars[0] = recon + scalars[3] + scalars[4] + scalars[6] + scalars[8];
+        scalars[15] = 0.0f;
+        if (step_guard_tripped(ga, gb)) poison_scalars(scalars);
     }
 }
 }  // namespace
@@ -264,7 +278,8 @@ namespace {
 // CE row sums -> stats[2Z+3], then the recon / total scalars: arcvae_stats_set_recon + arcvae_loss_finalize in one
 // launch (both sit in the exposed tail of the single-process step)
 __global__ __launch_bounds__(256) void recon_finalize_kernel(const float* __restrict__ rowloss, int n, float* stats,
-                                                             float* scalars, int Z, int T) {
+                                                             float* scalars, int Z, int T, const unsigned* ga,
+                                                             const unsigned* gb) {
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += rowloss[i];
     __shared__ float red[4];
@@ -277,6 +292,8 @@ __global__ __launch_bounds__(256) void recon_finalize_kernel(const float* __rest
         const float recon = ce / (stats[2 * Z + 2] * (float)T);
         scalars[1] = recon;
         scalars[0] = recon + scalars[3] + scalars[4] + scalars[6] + scalars[8];
+        scalars[15] = 0.0f;
+        if (step_guard_tripped(ga, gb)) poison_scalars(scalars);
     }
 }
 }  // namespace
@@ -284,15 +301,17 @@ __global__ __launch_bounds__(256) void recon_finalize_kernel(const float* __rest
 // stats[2Z+3] = sum_b rowloss[b], then as arcvae_loss_finalize: one launch (single-process step; under data
 // parallelism the CE sum is all-reduced between the two, so the two separate entry points stay)
 extern "C" int arcvae_recon_finalize(const float* rowloss, int B, float* stats, float* scalars, int Z, int T,
-                                     hipStream_t stream) {
+                                     const unsigned* guard_a, const unsigned* guard_b, hipStream_t stream) {
     if (!rowloss || !stats || !scalars || B <= 0 || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
-    hipLaunchKernelGGL(recon_finalize_kernel, dim3(1), dim3(256), 0, stream, rowloss, B, stats, scalars, Z, T);
+    hipLaunchKernelGGL(recon_finalize_kernel, dim3(1), dim3(256), 0, stream, rowloss, B, stats, scalars, Z, T, guard_a,
+                       guard_b);
     return arcvae_launch_status();
 }
 
-extern "C" int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, hipStream_t stream) {
+extern "C" int arcvae_loss_finalize(const float* stats, float* scalars, int Z, int T, const unsigned* guard_a,
+                                    const unsigned* guard_b, hipStream_t stream) {
     if (!stats || !scalars || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, scalars, Z, T);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, scalars, Z, T, guard_a, guard_b);
     return arcvae_launch_status();
 }
 

@@ -1037,12 +1037,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
 
 template <int NT, int LL, int RT, int MF = 0>
 void launch_persist(const PersistArgs& a, size_t lds, hipStream_t s) {
-    static bool attr_set = false;   // > 64 KB of dynamic LDS has to be allowed once per kernel (first call: eager step)
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL, RT, MF>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
+    // > 64 KB of dynamic LDS has to be allowed per kernel; set on every call (idempotent, no host state kept)
+    (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL, RT, MF>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL, RT, MF>), dim3(256), dim3(256), lds, s, a);
 }
 inline int persist_row_tiles(int B) { return ceil_div(B, 8) > 16 ? 2 : 1; }
@@ -1554,12 +1551,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
 
 template <int NT, int LL, int RT>
 void launch_persist_bwd(const PersistBwdArgs& a, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_kernel<NT, LL, RT>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute((const void*)lstm_bwd_persist_kernel<NT, LL, RT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipLaunchKernelGGL((lstm_bwd_persist_kernel<NT, LL, RT>), dim3(256), dim3(256), lds, s, a);
 }
 inline size_t persist_bwd_lds_bytes(int B, int H, int L) {
@@ -1604,23 +1597,7 @@ void launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t s) {
 
 inline bool hidden_ok(int H) { return H > 0 && (H % 64) == 0 && H <= 512; }
 
-// Diagnostic launch trace (tools/step_trace.py): slot s of the forward sweep at trace[2s..2s+1], of the BPTT sweep
-// at trace[2(cap/2 + s)..].  Set before the launches are recorded; null (default) = off.
-unsigned long long* g_trace = nullptr;
-int g_trace_cap = 0;
-inline unsigned long long* trace_slot(int slot) {
-    return (g_trace && slot >= 0 && slot < g_trace_cap) ? g_trace + 2 * (long)slot : nullptr;
-}
-
 }  // namespace
-
-// Diagnostic: device-side {start, end} stamps (100 MHz wall clock) of every step launch recorded after this call.
-// buf holds 2*cap u64; forward launch s -> slot s, BPTT launch s -> slot cap/2 + s.  buf = null switches it off.
-extern "C" int arcvae_set_step_trace(unsigned long long* buf, int cap) {
-    g_trace = buf;
-    g_trace_cap = buf ? cap : 0;
-    return ARCVAE_OK;
-}
 
 // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz; with wT_bwd also the BPTT layouts of
 // the same weights (keeps that launch off the chain between the sweeps) -- one launch for both when the 2(2L-1) jobs
@@ -1660,7 +1637,8 @@ static int tile_all_weights(const float* const* Wx, const float* const* Wh, floa
 extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq,
                                        float* hseq_t, float* cseq, float* gseq, float* wt, float* wT_bwd, int B,
-                                       int T, int V, int H, int L, hipStream_t stream) {
+                                       int T, int V, int H, int L, unsigned long long* trace,
+                                       hipStream_t stream) {
     if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !hseq_t || !cseq || !gseq || !wt) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || V <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
@@ -1680,7 +1658,7 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     const int RS = arcvae_ring_slots(T);
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
-        a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(s);
+        a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace ? trace + 2 * (long)s : nullptr;
         int nj = 0;
         for (int l = 0; l < L; ++l) {
             const int t = s - l;
@@ -1729,7 +1707,7 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
                                                   const float* const* Wh, const float* const* bias, float* hseq,
                                                   float* cseq, float* gseq, float* wt, float* wT_bwd,
                                                   unsigned* sync_ws, unsigned* start_signal, int B, int T, int V,
-                                                  int H, int L, hipStream_t stream) {
+                                                  int H, int L, unsigned long long* trace, hipStream_t stream) {
     if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq || !wt || !sync_ws) return ARCVAE_ERR_ARG;
     if (V <= 0 || !persist_shape_ok(B, T, H, L)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
@@ -1741,7 +1719,7 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
     PersistArgs a;
     a.x_tb = x_tb; a.table0 = table0; a.wt = wt; a.hseq = hseq; a.cseq = cseq; a.gseq = gseq;
     for (int l = 0; l < ARCVAE_MAX_LAYERS; ++l) a.bias[l] = (l > 0 && l < L) ? bias[l] : nullptr;
-    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace_slot(0);
+    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace;
     a.B = B; a.T = T; a.H = H; a.V = V; a.RX = ceil_div(B, 8); a.prio = arcvae_step_prio();
     const size_t lds = persist_lds_bytes(B, H, L);
     const int NT = H / 128;
@@ -1768,25 +1746,24 @@ extern "C" int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L) { r
 extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, const float* dh_top,
                                                    int ld_dh_top, float* dG, float* dcs, float* dxs, const float* wT,
                                                    unsigned* sync_ws, unsigned* start_signal, int B, int T, int H,
-                                                   int L, int s_begin, int s_end, hipStream_t stream) {
+                                                   int L, int s_begin, int s_end, int chunk_index,
+                                                   unsigned long long* trace, hipStream_t stream) {
     if (!cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !wT || !sync_ws) return ARCVAE_ERR_ARG;
     if (!persist_bwd_shape_ok(B, T, H, L) || ld_dh_top < H) return ARCVAE_ERR_ARG;
     const int S = T + 2 * (L - 1);
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
-    static int chunk_no = 0;   // role counters: a fresh set of 8 words per chunk launch of a sweep (zeroed at s_begin == 0)
-    if (s_begin == 0) {
+    // role counters: a fresh set of 8 words per chunk launch of a sweep (all zeroed by chunk 0)
+    if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
+    if (chunk_index == 0) {
         const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
         if (rc != ARCVAE_OK) return rc;
-        chunk_no = 0;
     }
-    if (chunk_no >= 8) return ARCVAE_ERR_ARG;
     PersistBwdArgs a;
     a.wT = wT; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
-    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace_slot(g_trace_cap / 2);
+    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace;
     a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
-    a.cnt_off = chunk_no == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_no - 1);   // chunk 0: words 256..263, then 272..
-    ++chunk_no;
+    a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);   // chunk 0: words 256..263, then 272..
     const size_t lds = persist_bwd_lds_bytes(B, H, L);
     const int NT = H / 128;
     const int RTn = persist_row_tiles(B);
@@ -1811,27 +1788,25 @@ extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, co
                                                       const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                                       float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
                                                       unsigned* start_signal, int B, int T, int H, int L, int s_begin,
-                                                      int s_end, hipStream_t stream) {
+                                                      int s_end, int chunk_index, unsigned long long* trace,
+                                                      hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !part_ws || !sync_ws) return ARCVAE_ERR_ARG;
     if (H != 256 || L < 1 || L > 2 || B < 1 || B > 64 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
     const int S = T + 2 * (L - 1);
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
-    static int chunk_no = 0;
-    if (s_begin == 0) {
+    if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
+    if (chunk_index == 0) {
         const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
         if (rc != ARCVAE_OK) return rc;
-        chunk_no = 0;
     }
-    if (chunk_no >= 8) return ARCVAE_ERR_ARG;
     PersistRsArgs ar;
     PersistBwdArgs& a = ar.b;
     a.wT = nullptr; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
-    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace_slot(g_trace_cap / 2);
+    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace;
     a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
-    a.cnt_off = chunk_no == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_no - 1);
-    ++chunk_no;
+    a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);
     if (L == 2) { ar.W[0] = Wh[1]; ar.W[1] = Wh[0]; ar.W[2] = Wx[1]; }
     else { ar.W[0] = Wh[0]; ar.W[1] = Wh[0]; ar.W[2] = Wh[0]; }
     for (int i = 0; i < 2 * L - 1; ++i) if (!ar.W[i]) return ARCVAE_ERR_ARG;
@@ -1873,7 +1848,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                         float* dG_t, float* dcs, float* dxs, float* wT, int B, int T, int H,
                                         int L, int s_begin, int s_end, int retile, unsigned* start_signal,
-                                        hipStream_t stream) {
+                                        unsigned long long* trace, hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
@@ -1901,7 +1876,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     const int RS = arcvae_ring_slots(T);
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
-        a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace_slot(g_trace_cap / 2 + s);
+        a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace ? trace + 2 * (long)s : nullptr;
         a.signal = (s == s_begin) ? start_signal : nullptr;
         int nj = 0;
         for (int l = L - 1; l >= 0; --l) {

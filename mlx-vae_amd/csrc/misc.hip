@@ -231,10 +231,16 @@ __global__ void transpose_tokens_kernel(const int32_t* __restrict__ src, int32_t
 // One launch over the flat [encoder | decoder] parameter buffer: the reference's two optimizers
 // share lr/betas/eps and Adam state is elementwise, so one flat pass is the same update.
 // HBM-bound: 4 streams read + 3 written = 28 B/param.
+// guard_a / guard_b (optional): device error words (an expired gate, a persistent sweep that gave up).  When either
+// is non-zero the gradients of this step are not trustworthy: nothing is updated, the parameters stay what they were.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n4, long n,
-                                                   float lr, float b1, float b2, float omb1, float omb2, float eps) {
+                                                   float lr, float b1, float b2, float omb1, float omb2, float eps,
+                                                   const unsigned* guard_a, const unsigned* guard_b) {
 #pragma clang fp contract(off)
+    if ((guard_a && __hip_atomic_load(guard_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
+        (guard_b && __hip_atomic_load(guard_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
+        return;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -382,8 +388,10 @@ extern "C" int arcvae_transpose_tokens(const int32_t* src, int32_t* dst, int B, 
 }
 
 // Reference: trainer.py:320,324 (optimizer.update) with MLX optim.Adam defaults (Q7).
+// guard_a / guard_b: optional device words; the update is skipped when either is non-zero (see adam_kernel).
 extern "C" int arcvae_adam_update(float* params, const float* grads, float* m, float* v, long n,
-                                  double lr, double beta1, double beta2, double eps, hipStream_t stream) {
+                                  double lr, double beta1, double beta2, double eps, const unsigned* guard_a,
+                                  const unsigned* guard_b, hipStream_t stream) {
     if (!params || !grads || !m || !v || n <= 0) return ARCVAE_ERR_ARG;
     const uintptr_t al = reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
                          reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v);
@@ -393,7 +401,7 @@ extern "C" int arcvae_adam_update(float* params, const float* grads, float* m, f
     const long work = n4 > 0 ? n4 : n;
     const int blocks = (int)min((long)2048, (work + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, m, v, n4, n, (float)lr,
-                       (float)beta1, (float)beta2, omb1, omb2, (float)eps);
+                       (float)beta1, (float)beta2, omb1, omb2, (float)eps, guard_a, guard_b);
     return arcvae_launch_status();
 }
 

@@ -133,17 +133,22 @@ class ARCVAETrainerWithLoss:
             # loss + grads + (no-op clip, Q6) + both Adam updates: one captured step
             out, _ = api.value_and_grad(self.encoder, self.decoder, molecules, conditions,
                                         teacher_forcing_ratio=teacher_forcing_ratio, lr=self.learning_rate, **hyper)
-            loss_t = out["total_loss"]
+            loss_st = out["loss_and_status"]   # [total_loss, step status]: read together, one host sync per batch
             if batch_idx == 0 or batch_idx % 25 == 0:  # Q16: second forward, post-update weights, T more coins
                 d = self._loss_dict(molecules, conditions, beta, teacher_forcing_ratio)
-                vals = torch.stack([loss_t, d["recon_loss"], d["kl_loss"], d["collapse_penalty"],
-                                    d["prop_loss"]]).tolist()
-                loss_val = vals[0]
-                for k, v in zip(("recon", "kl", "collapse", "prop"), vals[1:]):
+                vals = torch.cat([loss_st, torch.stack([d["recon_loss"], d["kl_loss"], d["collapse_penalty"],
+                                                        d["prop_loss"]])]).tolist()
+                loss_val, status = vals[0], vals[1]
+                for k, v in zip(("recon", "kl", "collapse", "prop"), vals[2:]):
                     sums[k] += v
                 comp_count += 1
             else:
-                loss_val = float(loss_t)  # the reference syncs here too (trainer.py:366)
+                loss_val, status = loss_st.tolist()  # the reference syncs here too (trainer.py:366)
+            if status != 0.0:
+                # a device-side gate expired or a persistent sweep gave up in THIS step: the device has already
+                # skipped both Adam updates (the weights are those of the previous batch); stop here, not at epoch end
+                self.engine.check_gates()
+                raise RuntimeError(f"training step {batch_idx}: stream order was lost on the device (no update applied)")
             if not np.isfinite(loss_val) or loss_val > 2000.0 or loss_val < -10.0:  # Q15
                 print(f"\nWARNING: loss explosion detected at batch {batch_idx}: {loss_val:.2e} "
                       "(update already applied; value excluded from the epoch mean)")

@@ -134,7 +134,7 @@ def synthetic_batch(cfg: Config, B: int, T: int, seed: int = 67):
     lengths = rs.randint(lo, hi, size=B)
     x = np.zeros((B, T), dtype=np.int64)
     for b in range(B):
-        n = int(lengths[b])
+        n = min(int(lengths[b]), T - 1)          # (T == 1: the row is just the EOS token)
         x[b, :n] = rs.randint(3, cfg.V, size=n)
         x[b, n] = 2
     cond = rs.standard_normal((B, cfg.C)).astype(np.float32)

@@ -7,14 +7,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "arcvae_hip.h")
 
 
-def _declared():
+def _declared_args():
+    """name -> list of C parameter declarations (comments stripped, whitespace normalised)."""
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
     for m in re.finditer(r"\bint\s+(arcvae_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
-        args = [a.strip() for a in m.group(2).split(",") if a.strip()]
-        decls[m.group(1)] = len(args)
+        decls[m.group(1)] = [" ".join(a.split()) for a in m.group(2).split(",") if a.strip()]
     return decls
+
+
+def _declared():
+    return {k: len(v) for k, v in _declared_args().items()}
+
+
+def _ctype_of(decl: str):
+    """The ctypes class a C parameter declaration must be bound with (the binding's conventions: pointer-to-pointer
+    = POINTER(c_void_p) host arrays of device pointers, int* = POINTER(c_int) host arrays, every other pointer and the
+    stream = c_void_p)."""
+    ty = re.sub(r"\b\w+$", "", decl).strip() if not decl.endswith("*") else decl   # drop the parameter name
+    ty = ty.replace("const", "").replace(" ", "")
+    if ty.count("*") == 2:
+        return ctypes.POINTER(ctypes.c_void_p)
+    if ty == "int*":
+        return ctypes.POINTER(ctypes.c_int)
+    if "*" in ty or ty == "arcvae_stream_t":
+        return ctypes.c_void_p
+    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+            "unsigned": ctypes.c_uint, "unsignedint": ctypes.c_uint}[ty]
 
 
 def test_header_declares_the_path():
@@ -38,6 +58,32 @@ def test_binding_signatures_match_header_arity():
     assert set(_lib.SIGNATURES) == set(d), set(_lib.SIGNATURES) ^ set(d)
     for name, n in d.items():
         assert len(_lib.SIGNATURES[name]) == n, (name, len(_lib.SIGNATURES[name]), n)
+
+
+def test_binding_signatures_match_header_types():
+    """Every parameter's C type in include/arcvae_hip.h against the ctypes class it is bound with -- not just the
+    count: an int bound as a pointer (or a double as a float) would pass the arity check and corrupt the call."""
+    from arcvae_hip import _lib
+    for name, decls in _declared_args().items():
+        want = [_ctype_of(d) for d in decls]
+        got = _lib.SIGNATURES[name]
+        for i, (w, g, d) in enumerate(zip(want, got, decls)):
+            assert w is g or (w == g), (name, i, d, w, g)
+
+
+def test_header_keeps_no_hidden_host_state():
+    """The header promises re-entrancy: no entry point may depend on a previous call through mutable host globals.
+    Checked at the source level: no mutable `static` / namespace-scope variable in csrc (read-once `static const`
+    environment knobs excepted), and no set-and-forget entry point in the ABI."""
+    src_dir = os.path.join(ROOT, "mlx-vae_amd", "csrc")
+    for fn in os.listdir(src_dir):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        for ln, line in enumerate(open(os.path.join(src_dir, fn)), 1):
+            code = line.split("//")[0]
+            if re.search(r"^\s*static\s+(?!const|inline|constexpr|__device__|int tile_all_weights)", code) and "static_assert" not in code:
+                raise AssertionError(f"{fn}:{ln}: mutable static host state: {line.strip()}")
+    assert "arcvae_set_step_trace" not in _declared()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

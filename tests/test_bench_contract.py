@@ -1,13 +1,39 @@
-"""The bench line the driver parses (bench.py prints exactly this object on stdout): schema check on the committed
-run profiles/r01_bench.json, so that a change to bench.py that drops or renames a field fails on CPU."""
+"""The bench line the driver parses (bench.py prints exactly this object on stdout): schema check on the newest
+committed run profiles/r*_bench.json, so that a change to bench.py that drops or renames a field fails on CPU; and the
+self-launch path of `python bench.py --gpus N` (no GPU needed: --dry-launch prints the command of the child)."""
+import glob
 import json
 import os
+import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest_bench():
+    return json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))[-1]))
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 8` (the command shape the driver uses at N = 1) must not die on a missing WORLD_SIZE:
+    it launches torch.distributed.run as a child.  --dry-launch shows that command without touching a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "3",
+                        "--dry-launch"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "7", "--warmup", "3"]        # same arguments, minus --dry-launch
+    # one GPU: nothing to launch
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-launch"], capture_output=True, text=True,
+                        env=env, timeout=120)
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip())["launch"] is None
+
+
 def test_committed_bench_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    d = _newest_bench()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -29,5 +55,6 @@ def test_committed_bench_line_has_every_contract_field():
 def test_bench_source_names_the_contract_fields():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for k in ('"metric"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"',
-              '"roofline"', '"cpu_baseline"', '"workload"'):
+              '"roofline"', '"cpu_baseline"', '"workload"', '"strong"', '"n_ranks_seen"', '"step_tflops_executed"',
+              '"tick_model"', '"limiter"'):
         assert k in src, k

@@ -52,7 +52,7 @@ class _Plan:
     def heads(self, phase):
         pass
 
-    def sweep(self, s0, s1, start_signal=None):
+    def sweep(self, s0, s1, start_signal=None, chunk_index=0):
         c = [i for i, ch in enumerate(self.chunks) if ch[0] == s0][0]
         if start_signal is not None:            # raised by the first launch of the chunk when it starts
             assert start_signal == ("word", E.Gates.P)

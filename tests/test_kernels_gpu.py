@@ -81,7 +81,7 @@ def test_adam_matches_mlx_formula():
     dp, dg, dm, dv = _dev(p), _dev(g), _dev(m), _dev(v)
     for _ in range(3):
         call("arcvae_adam_update", ptr(dp), ptr(dg), ptr(dm), ptr(dv), C.c_long(n), 2e-4, 0.9, 0.999, 1e-8,
-             stream_ptr())
+             None, None, stream_ptr())
     torch.cuda.synchronize()
     pp, mm, vv = p.copy(), m.copy(), v.copy()
     f = np.float32
@@ -94,6 +94,30 @@ def test_adam_matches_mlx_formula():
     assert rel_err(out, pp) < 1e-6
     assert rel_err(dm.cpu().numpy(), mm) < 1e-6
     # step-1 identity from SURVEY section 4: update = lr*0.1g / (sqrt(0.001) |g| + 1e-8)
+
+
+def test_adam_skips_the_update_when_a_guard_word_is_set():
+    """An expired gate / a persistent sweep that gave up leaves a non-zero device word: the Adam kernel must then leave
+    parameters and state untouched (gradients formed after a lost stream order destroyed the weights)."""
+    from arcvae_hip._lib import call, ptr, stream_ptr
+    import ctypes as C
+    rs = np.random.RandomState(2)
+    n = 4096 + 5
+    p, g = rs.standard_normal(n).astype(np.float32), rs.standard_normal(n).astype(np.float32)
+    dp, dg, dm, dv = _dev(p), _dev(g), _dev(np.zeros(n, np.float32)), _dev(np.zeros(n, np.float32))
+    words = torch.zeros(64, dtype=torch.int32, device="cuda")
+    wa, wb = C.c_void_p(words.data_ptr()), C.c_void_p(words.data_ptr() + 128)
+    for tripped in ((1, 0), (0, 3)):
+        words[0], words[32] = tripped
+        call("arcvae_adam_update", ptr(dp), ptr(dg), ptr(dm), ptr(dv), C.c_long(n), 2e-4, 0.9, 0.999, 1e-8, wa, wb,
+             stream_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(dp.cpu().numpy(), p) and float(dm.abs().max()) == 0.0 and float(dv.abs().max()) == 0.0
+    words.zero_()
+    call("arcvae_adam_update", ptr(dp), ptr(dg), ptr(dm), ptr(dv), C.c_long(n), 2e-4, 0.9, 0.999, 1e-8, wa, wb,
+         stream_ptr())
+    torch.cuda.synchronize()
+    assert not np.array_equal(dp.cpu().numpy(), p) and float(dm.abs().max()) > 0.0
 
 
 def test_segsum_and_colsum():

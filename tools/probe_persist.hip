@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
     const int arow = xcc * ROWS + (r & 7);          // rows 8..15 of the MFMA tile repeat rows 0..7 (ignored)
     float cst = 0.f;                                // cell state of my (row, unit) stays in a register
     for (int t = 0; t < a.T; ++t) {
-        if (MODE == 4) {
+        if (MODE >= 4 && MODE != 7) {
             // ---- tagged exchange: my A operands ARE the synchronisation.  Lane (r, q4) of wave w needs k = 16c + q4 .. +3
             // of its row for its 4 chunks: 4 pairs = 32 B = two 16-byte loads per chunk and source.
             const uint2* hb = a.hx + (long)(t & 1) * NSRC * 64 * H;
@@ -78,7 +78,14 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const u32x4* p = reinterpret_cast<const u32x4*>(hb + ((long)s * 64 + arow) * H + (wave * 4 + c) * 16 + q4);
-                        const u32x4 lo = __builtin_nontemporal_load(p), hi = __builtin_nontemporal_load(p + 1);
+                        u32x4 lo, hi;
+                        if (MODE == 4) { lo = __builtin_nontemporal_load(p); hi = __builtin_nontemporal_load(p + 1); }
+                        else {   // MODE 5, 6, 8: agent-scope (sc1) 16-byte loads: bypass L1 by the memory model, not by a hint
+                            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, NSRC * 64 * H * 8, 0x00020000);
+                            const unsigned off = (unsigned)((((long)s * 64 + arow) * H + (wave * 4 + c) * 16 + q4) * 8);
+                            lo = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+                            hi = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16);
+                        }
                         fa[s][c] = f32x4{__uint_as_float(lo.x), __uint_as_float(lo.z), __uint_as_float(hi.x), __uint_as_float(hi.z)};
                         ok = ok && lo.y == (unsigned)t && lo.w == (unsigned)t && hi.y == (unsigned)t && hi.w == (unsigned)t;
                     }
@@ -100,21 +107,28 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][c].w, w.w, acc[n], 0, 0, 0);
                     }
                 }
-            __syncthreads();                       // red of the previous tick has been read by everybody
+            float* redt = red;
+            if (MODE == 8) redt = red + (t & 1) * 2048;   // double-buffered reduction tile: ONE block barrier per tick
+            else __syncthreads();                  // red of the previous tick has been read by everybody
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) red[wave * 512 + ((lane >> 4) * 4 + reg) * 32 + 16 * n + r] = acc[n][reg];
+                for (int reg = 0; reg < 4; ++reg) redt[wave * 512 + ((lane >> 4) * 4 + reg) * 32 + 16 * n + r] = acc[n][reg];
             __syncthreads();
             {
                 const int row = tid >> 5, col = tid & 31;
-                float v = (red[row * 32 + col] + red[512 + row * 32 + col]) + (red[1024 + row * 32 + col] + red[1536 + row * 32 + col]);
+                float v = (redt[row * 32 + col] + redt[512 + row * 32 + col]) + (redt[1024 + row * 32 + col] + redt[1536 + row * 32 + col]);
                 const float g = tanhf(v * 0.01f);
                 cst = 0.5f * cst + g;
                 uint2* ho = a.hx + (long)((t + 1) & 1) * NSRC * 64 * H;
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s)       // one 8-byte store per value: the tag arrives with it or not at all
-                    if (col < 8) ho[((long)s * 64 + xcc * ROWS + row) * H + role * 8 + col] = make_uint2(__float_as_uint(cst), (unsigned)(t + 1));
+                    if (col < 8) {
+                        uint2* dst = ho + ((long)s * 64 + xcc * ROWS + row) * H + role * 8 + col;
+                        const unsigned long long pk = ((unsigned long long)(unsigned)(t + 1) << 32) | __float_as_uint(cst);
+                        if (MODE == 6) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through, drops the L2 line
+                        else *dst = make_uint2(__float_as_uint(cst), (unsigned)(t + 1));
+                    }
             }
             continue;
         }
@@ -142,8 +156,14 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
 #pragma unroll
         for (int s = 0; s < NSRC; ++s)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)           // wave w owns chunks [4w, 4w+4) of the 16 chunks of a source
+            for (int c = 0; c < 4; ++c) {         // wave w owns chunks [4w, 4w+4) of the 16 chunks of a source
+                if (MODE == 7) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, NSRC * 64 * H * 4, 0x00020000);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((((long)s * 64 + arow) * H + (wave * 4 + c) * 16 + q4) * 4), 0, 16);
+                    fa[s][c] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                } else
                 fa[s][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(hb + ((long)s * 64 + arow) * H + (wave * 4 + c) * 16 + q4));
+            }
         if (MODE == 1) {
             float sum = 0.f;
 #pragma unroll
@@ -195,7 +215,10 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my stores have reached L2 (a workgroup-scope release fence emits no vmcnt wait)
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.flags + xcc * 32 + role, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store: stays in the XCD's L2
+        if (tid == 0) {
+            if (MODE == 7) __hip_atomic_store(a.flags + xcc * 32 + role, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 flag store
+            else __hip_atomic_store(a.flags + xcc * 32 + role, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store: stays in the XCD's L2
+        }
     }
 }
 
@@ -229,12 +252,16 @@ int main() {
     CK(hipMalloc(&a.hx, (size_t)2 * NSRC * 64 * H * 8));
     CK(hipMalloc(&a.flags, NXCD * 32 * 4)); CK(hipMalloc(&a.cnt, NXCD * 4)); CK(hipMalloc(&a.info, 256 * 2 * 4)); CK(hipMalloc(&a.err, 4));
     a.W = W;
-    const int lds_bytes = (NSRC * 16 * COLS * 16 + 4 * 16 * 32) * 4;
+    const int lds_bytes = (NSRC * 16 * COLS * 16 + 2 * 4 * 16 * 32) * 4;
     printf("persistent per-XCD recurrence probe: T = %d ticks, %d KB LDS per block\n", a.T, lds_bytes / 1024);
     if (run<0>("barrier only (32-CU flag line per XCD)", a, lds_bytes)) return 1;
     if (run<1>("+ A operand loads (L1-bypassing)", a, lds_bytes)) return 1;
     if (run<2>("+ 96 MFMAs per wave, W from LDS", a, lds_bytes)) return 1;
     if (run<3>("+ reduce, cell update, h stores (full tick)", a, lds_bytes)) return 1;
-    if (run<4>("full tick, tagged exchange (no flags)", a, lds_bytes)) return 1;
+    if (run<7>("full tick, flags: sc1 data loads + agent flag store", a, lds_bytes)) return 1;
+    if (run<4>("tagged exchange: nt loads, plain stores", a, lds_bytes)) return 1;
+    if (run<5>("tagged exchange: sc1 loads, plain stores", a, lds_bytes)) return 1;
+    if (run<6>("tagged exchange: sc1 loads, sc1 stores", a, lds_bytes)) return 1;
+    if (run<8>("tagged: sc1 loads, plain stores, 1 barrier", a, lds_bytes)) return 1;
     return 0;
 }

@@ -1,7 +1,7 @@
 """Device-side launch trace of the LSTM sweeps inside a real training step (no profiler attached):
 python tools/step_trace.py [--batch 64] [--steps 30]
 Every step launch stamps the 100 MHz wall clock at the start and end of its block (0,0,0)
-(arcvae_set_step_trace).  Prints cadence (start-to-start) statistics, the gaps, and a coarse timeline."""
+(the `trace` argument of the sweep entry points).  Prints cadence (start-to-start) statistics, the gaps, and a coarse timeline."""
 import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,7 +41,7 @@ ws.x.copy_(torch.tensor(x)); ws.cond.copy_(torch.tensor(cond))
 ws.eps.copy_(torch.tensor(rs.standard_normal((B, Z)).astype(np.float32)))
 cap = 2 * (T + 2 * L + 4)
 buf = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
-_lib.call("arcvae_set_step_trace", _lib.ptr(buf), cap)
+ws.trace_fwd, ws.trace_bwd = buf[:cap], buf[cap:]   # forward launch s -> slot s, BPTT launch s -> slot cap/2 + s
 if args.dp:
     import torch.distributed as dist
     from arcvae_hip.dp import DataParallelStep, EngineOps
@@ -98,9 +98,9 @@ wx, _k1 = E._layer_ptrs(enc, L, "Wx", skip0=True)
 wh, _k2 = E._layer_ptrs(enc, L, "Wh")
 bs, _k3 = E._layer_ptrs(enc, L, "bias", skip0=True)
 alone("forward sweep", lambda: E.call("arcvae_enc_lstm_forward", E.ptr(ws.x_tb), E.ptr(ws.table0), wx, wh, bs, E.ptr(ws.hseq),
-      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, E.stream_ptr()), nf, 0)
+      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, E.ptr(ws.trace_fwd), E.stream_ptr()), nf, 0)
 alone("BPTT sweep", lambda: E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * H,
-      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, None, E.stream_ptr()), nb, cap // 2)
+      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, None, E.ptr(ws.trace_bwd), E.stream_ptr()), nb, cap // 2)
 
 # ---- hypothesis checks -------------------------------------------------------------------------------
 big = torch.empty(160 * 1024 * 1024, dtype=torch.float32, device=dev)  # 640 MB: evicts the 256 MB Infinity Cache
@@ -116,9 +116,9 @@ def alone_cold(name, fn, n, off):
     a = buf.cpu().numpy().reshape(cap, 2).astype(np.float64)[off:off + n] / 100.0
     stats(name + " ALONE after a 640 MB write (Infinity Cache evicted)", a - a[0, 0])
 alone_cold("forward sweep", lambda: E.call("arcvae_enc_lstm_forward", E.ptr(ws.x_tb), E.ptr(ws.table0), wx, wh, bs, E.ptr(ws.hseq),
-      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, E.stream_ptr()), nf, 0)
+      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, E.ptr(ws.trace_fwd), E.stream_ptr()), nf, 0)
 alone_cold("BPTT sweep", lambda: E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * H,
-      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, None, E.stream_ptr()), nb, cap // 2)
+      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, None, E.ptr(ws.trace_bwd), E.stream_ptr()), nb, cap // 2)
 
 # the engine's own forward segment, replayed with nothing else in flight
 run = E.SegmentRunner(True)
