@@ -8,12 +8,14 @@ step needs exactly two exchanges:
   1. forward seam : all-reduce(SUM) of `stats` (2Z+4 floats: sum mu, sum exp(logvar), KL sums,
                     row count, CE row-sum) -> every rank evaluates the GLOBAL loss scalars and
                     the MI gate, and differentiates them w.r.t. its LOCAL rows (1/B_global scaling);
-  2. backward     : all-reduce(SUM) of the flat gradient buffers -- one contiguous bucket [enc.grad |
-                    dec.grad | CE sum] reduced in two pieces on the main stream behind the BPTT sweep (gated
-                    form, see EngineOps), or one bucket per module with the decoder's reduced on a comm stream
-                    beside the sweep (event form).  Messages are <= 5.3 MB: on point-to-point xGMI RCCL
-                    picks a direct reduce-scatter/all-gather rather than a per-link-bound ring (SURVEY
-                    section 5).
+  2. backward     : all-reduce(SUM) of the flat gradient buffers in readiness order (north_star:
+                    "overlapped with the backward LSTM sweep"): the decoder's share [dec.grad | CE sum]
+                    (3.9 MB) is complete ~0.6 ms before the encoder's -- the decoder never reads z (Q2) -- and
+                    is reduced on the SIDE stream right behind the decoder's backward, through a SECOND
+                    communicator, i.e. beside the BPTT sweep; the encoder's share (5.3 MB) is reduced on
+                    the main stream after the sweep's last weight-gradient chunk.  Messages are <= 5.3 MB:
+                    on point-to-point xGMI RCCL picks a direct reduce-scatter/all-gather rather than a
+                    per-link-bound ring.
 
 Teacher-forcing coins, weights and Adam state must be identical on all ranks (same seed / same
 reduced gradients); `DataParallelStep` never touches them.
@@ -39,12 +41,17 @@ class StepOps(Protocol):
     stats: torch.Tensor        # per-rank partial latent sums (2Z+3 floats), all-reduced before the backward
     recon_stat: Optional[torch.Tensor]  # per-rank CE sum (1 float); None when it travels inside a gradient bucket
 
-    def forward_local(self) -> None: ...      # fills self.stats with this rank's partial sums
-    def backward_local(self) -> None: ...     # self.stats now holds GLOBAL sums; fills all gradients
-    def early_buckets(self) -> List[torch.Tensor]: ...  # gradients ready before backward_local completes
+    def forward_local(self) -> None: ...      # fills self.stats with this rank's partial sums; starts the decoder
+    def backward_local(self) -> None: ...     # self.stats now holds GLOBAL sums; fills the encoder's gradients
+    def early_buckets(self) -> List[torch.Tensor]: ...  # gradients that do not depend on the stats seam (decoder)
+    def early_done(self) -> None:
+        if self.gated:
+            self._dec_adam_gated()                   # decoder gradients are GLOBAL: its Adam update rides on side too
+
     def late_buckets(self) -> List[torch.Tensor]: ...   # gradients ready after backward_local
     def early_context(self) -> ContextManager: ...      # stream context the early reduces are issued from
     def recon_local(self) -> None: ...        # fills the CE sum (inside early_context)
+    def early_done(self) -> None: ...         # optional: early buckets are GLOBAL (inside early_context)
     def apply_update(self) -> None: ...       # the CE sum is GLOBAL by now
 
 
@@ -53,28 +60,43 @@ class DataParallelStep:
     runs an RCCL collective ON that stream, so no internal communication stream sits blocked on an event beside the
     running LSTM chain (a blocked hardware queue costs ~1 us per dependent launch on MI355X, engine.Gates)."""
 
-    def __init__(self, ops: StepOps, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, ops: StepOps, group: Optional[dist.ProcessGroup] = None,
+                 early_group: Optional[dist.ProcessGroup] = None):
+        """group: communicator of the stats seam and the late (encoder) bucket.  early_group: communicator of the
+        early (decoder) bucket -- a SECOND one, because those reduces are issued from another stream and run
+        concurrently with the first group's; created here (collectively: every rank constructs its driver) when not
+        given.  Per communicator the issue order is the same on every rank: {stats, late buckets} and {CE sum, early
+        buckets}."""
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # exercise the collectives even at world size 1 (single-GPU rehearsal of the N-rank path)
         self.force = os.environ.get("ARCVAE_DP_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+        self.early_group = early_group
+        if early_group is None and dist.is_initialized() and (self.world > 1 or self.force):
+            self.early_group = dist.new_group()         # all ranks, same backend as the default group
+        warm = getattr(ops, "warm_up", None)
+        if warm is not None and self.early_group is not None:
+            warm(self.early_group)                      # set the second communicator up before any gate can wait behind it
 
-    def _all_reduce(self, t: Optional[torch.Tensor]) -> None:
+    def _all_reduce(self, t: Optional[torch.Tensor], group=None) -> None:
         if t is None or (self.world == 1 and not self.force):
             return
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group if group is not None else self.group)
 
     def step(self) -> None:
         ops = self.ops
         ops.forward_local()
+        with ops.early_context():                       # decoder-side results: independent of the stats seam (Q2), so
+            ops.recon_local()                           # issued first -- they run beside the encoder's sweeps
+            self._all_reduce(ops.recon_stat, self.early_group)
+            for g in ops.early_buckets():
+                self._all_reduce(g, self.early_group)
+            done = getattr(ops, "early_done", None)
+            if done is not None:
+                done()
         self._all_reduce(ops.stats)                     # forward seam (critical path, 2Z+3 floats)
         ops.backward_local()
-        with ops.early_context():                       # decoder-side results
-            ops.recon_local()
-            self._all_reduce(ops.recon_stat)
-            for g in ops.early_buckets():
-                self._all_reduce(g)
         for g in ops.late_buckets():
             self._all_reduce(g)
         ops.apply_update()
@@ -85,16 +107,16 @@ class EngineOps:
 
     Gated form (default; engine.Gates -- side/aux wait in device-side gate kernels, no blocked hardware queue):
       main stream : signal -> [enc_fwd] -> (all-reduce stats) -> [loss + dcomb + sweep chunks + signals]
-                    -> gate on side's decoder -> [CE sum] -> (all-reduce dec.grad | CE sum: overlaps the last
-                    weight-gradient chunk on aux / side) -> join aux, side -> (all-reduce enc.grad) -> [finalize + adam]
-      side stream : gate -> [dec_fwd + dec_bwd] ... gate -> [tail chunk's token-table half]
+                    -> join aux, side -> (all-reduce enc.grad) -> [finalize + encoder adam]
+      side stream : gate -> [dec_fwd + dec_bwd] -> [CE sum] -> (all-reduce dec.grad | CE sum, SECOND communicator)
+                    -> [decoder adam] ... gate -> [weight-gradient pieces of the sweep chunks]
       aux stream  : gate -> [weight gradients of chunk c] ...
-      Three collectives per step, all on the main stream and one communicator (issue order = execution order on
-      every rank).  The gradient bucket is one contiguous buffer (the stores' `grad` tensors are re-pointed into it)
-      reduced in two pieces: the decoder's 3.9 MB right behind the sweep, beside the tail of the weight-gradient
-      work, the encoder's 5.3 MB after the join.  The decoder's share is not overlapped with the BPTT sweep itself
-      any more (that needed a second stream blocked on events), which buys a step without any cross-stream event
-      wait while the chain runs.
+      The gradient bucket is one contiguous buffer (the stores' `grad` tensors are re-pointed into it) reduced in
+      two pieces: the decoder's 3.9 MB in SIDE's stream order right behind the decoder's backward -- no event, no
+      gate: the collective is just the next operation of that stream, so nothing sits blocked beside the chain --
+      which puts it beside the encoder's forward / BPTT sweeps (north_star: "overlapped with the backward LSTM
+      sweep"); the encoder's 5.3 MB on main after the join.  Two communicators, each used from exactly one stream
+      with the same issue order on every rank ({stats, enc.grad} on main's, {dec bucket} on side's).
 
     Event form (fallback when the gate probe fails, ARCVAE_GATES=0): as in round 1 --
       side: [dec_fwd] -> ev_chain -> [dec_bwd] -> ev_dec_bwd;  comm stream: CE sum and dec.grad reduced beside the
@@ -125,6 +147,15 @@ class EngineOps:
         else:
             self.recon_stat = ws.stats[2 * Z + 3:2 * Z + 4]
             self.comm = torch.cuda.Stream(device=engine.device)
+
+    def warm_up(self, group) -> None:
+        """First collective of a communicator (channel / IPC set-up: seconds on 8 GPUs) outside the step, on the stream
+        that will use it."""
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            with torch.cuda.stream(self.eng.side):
+                t = torch.zeros(1024, dtype=torch.float32, device=self.eng.device)
+                dist.all_reduce(t, group=group)
+            torch.cuda.synchronize()
 
     def _make_bucket(self) -> None:
         """One contiguous gradient bucket [enc.grad | dec.grad | CE sum]; recorded segments hold the old pointers,
@@ -161,17 +192,18 @@ class EngineOps:
                             gate=(g, nc < 2))
 
     def _recon_gated(self) -> None:
-        # behind the BPTT sweep on main: once side reports its decoder segment done (gate on D: finished ~1 ms ago),
-        # CE row sums -> the bucket's last cell; the [dec.grad | CE sum] half of the bucket is then reduced while
-        # aux and side are still busy with the last chunk's weight gradients
-        eng, ws, g = self.eng, self.ws, self.eng.gates
+        # on SIDE, in stream order right behind the decoder's backward: CE row sums -> the bucket's last cell, so that
+        # the [dec.grad | CE sum] half of the bucket is one message
+        eng, ws = self.eng, self.ws
         Z = eng.d.Z
         base = C.c_void_p(self.bucket_recon.data_ptr() - 4 * (2 * Z + 3))
+        self.run("dp_recon", lambda: call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, base, Z, stream_ptr()),
+                 torch.cuda.current_stream())
 
-        def fn():
-            g.wait(g.D, g.NM, 1, 1)    # ticket of main's current step; NM is advanced by the join below
-            call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, base, Z, stream_ptr())
-        self.run("dp_recon", fn, torch.cuda.current_stream())
+    def _dec_adam_gated(self) -> None:
+        from .engine import adam_update
+        eng, ws = self.eng, self.ws
+        self.run("dp_dec_adam", lambda: adam_update(eng.dec, self.lr, guards=eng.guards(ws)), torch.cuda.current_stream())
 
     def _join_gated(self) -> None:
         self.run("dp_join", self.eng.gates.join, torch.cuda.current_stream())  # aux and side reported their last piece
@@ -182,10 +214,9 @@ class EngineOps:
         Z = eng.d.Z
 
         def fn():
-            ws.stats[2 * Z + 3:2 * Z + 4].copy_(self.bucket_recon)   # GLOBAL CE sum
+            ws.stats[2 * Z + 3:2 * Z + 4].copy_(self.bucket_recon)   # GLOBAL CE sum (side reduced it long ago)
             ga, gb = eng.guards(ws)
             call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), Z, ws.T, ga, gb, stream_ptr())
-            adam_update(eng.dec, self.lr, guards=(ga, gb))
             adam_update(eng.enc, self.lr, guards=(ga, gb))
         self.run("dp_finish", fn, torch.cuda.current_stream())
 
@@ -202,14 +233,15 @@ class EngineOps:
 
     def backward_local(self) -> None:
         if self.gated:
-            self.eng.enqueue_backward(self.ws, self._grun, gates=self.eng.gates)  # joined in _recon_gated
+            self.eng.enqueue_backward(self.ws, self._grun, gates=self.eng.gates)  # joined in late_buckets
             return
         self.eng.enqueue_backward(self.ws, self.run)
 
     @contextlib.contextmanager
     def early_context(self):
         if self.gated:
-            yield
+            with torch.cuda.stream(self.eng.side):   # the decoder's stream: its reduces are that stream's next operations
+                yield
             return
         # decoder-side collectives are issued from the comm stream so they do not queue behind BPTT
         self.comm.wait_event(self.eng.ev_enc_fwd)  # the encoder forward zero-fills `stats` before the CE slot is set
@@ -227,6 +259,10 @@ class EngineOps:
             return [self.bucket_dec]
         torch.cuda.current_stream().wait_event(self.eng.ev_dec_bwd)
         return [self.eng.dec.grad]
+
+    def early_done(self) -> None:
+        if self.gated:
+            self._dec_adam_gated()                   # decoder gradients are GLOBAL: its Adam update rides on side too
 
     def late_buckets(self) -> List[torch.Tensor]:
         if self.gated:

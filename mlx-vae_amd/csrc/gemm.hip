@@ -238,6 +238,174 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
     }
 }
 
+// ---- split-bf16 ("bf16x3") TN GEMM: fp32 accuracy on the bf16 matrix cores --------------------------------------------
+// C[M,N] += A^T . B with A stored [K,M], B stored [K,N] (the weight-gradient shape: K = time x batch, long; M, N =
+// weight dims).  The exact-f32 MFMA runs at 1/16 of the bf16 rate and holds a SIMD's matrix pipe 64 cycles per K = 2; the
+// weight-gradient GEMMs beside the BPTT sweep are the largest consumers of that pipe on the sweep's own CUs.  Here every
+// f32 operand is split into three bf16 pieces, x = hi + mid + lo (8 + 8 + 8 significant bits: exact up to the last
+// rounding), and a product is the six terms of weight >= 2^-16: hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid, all
+// accumulated in f32 by v_mfma_f32_32x32x16_bf16 -- 6 x 32 cycles per K = 16 instead of 8 x 64: 2.7x less matrix-pipe time,
+// error ~2^-22 of |a||b| per product (the dropped terms), i.e. the accuracy class of an f32 fmaf chain (tests compare both
+// against fp64).
+// No LDS, no barrier, one wave per 128 x 64 output tile and K slice: a lane loads its operands straight into the MFMA
+// fragment layout.  A fragment needs 8 consecutive k of ONE row per lane, but k is the slow index of both operands, so a
+// lane takes 8 loads (k = 8h .. 8h+7) of 4 consecutive m (one float4: lanes r = 0..31 cover 512 contiguous bytes) and the
+// four m feed the four 32-row MFMA tiles of the wave: tile i holds rows m0 + 4r + i (an interleaved row order, undone
+// in the epilogue's row index); B columns stay natural (n0 + 32j + c, dword loads: 128 contiguous bytes per half-wave),
+// so the epilogue's float atomics cover two full 128-B row segments per wave-instruction (the full-rate shape).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_g __attribute__((ext_vector_type(4)));
+
+struct SplitTN {
+    const float* A;   // [K, M]
+    const float* B;   // [K, N]
+    float* C;         // [M, N], +=
+    int M, N, K, lda, ldb, ldc, kchunk;
+};
+#define ARCVAE_SPLIT_GROUP_MAX 8
+struct SplitTNGroup {
+    SplitTN p[ARCVAE_SPLIT_GROUP_MAX];
+    int zoff[ARCVAE_SPLIT_GROUP_MAX + 1];
+    int n;
+};
+
+__device__ __forceinline__ unsigned split_pk(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// (x0, x1) -> packed bf16 pairs hi, mid, lo with x = hi + mid + lo (the two subtractions are exact in f32)
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = split_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = split_pk(r0, r1);
+    lo = split_pk(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
+}
+
+template <int NJ>   // wave tile: 128 rows (4 interleaved 32-row tiles) x 32*NJ columns
+__device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, const int by, const int bz) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int m0 = by * 128, n0 = bx * 32 * NJ;
+    const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    const int am = m0 + 4 * r;                     // my 4 rows (columns of the stored A): am .. am + 3
+    const bool aok = am < p.M;                     // M % 4 == 0: all four or none
+    f32x16 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float4 ra[8];
+    float rb[8][NJ];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = k0 + 8 * h + kk;
+            const bool kok = k < kend;
+            ra[kk] = (kok && aok) ? *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + am) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + 32 * j + r;
+                rb[kk][j] = (kok && n < p.N) ? p.B[(long)k * p.ldb + n] : 0.f;
+            }
+        }
+    };
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        // fragments of this K = 16 step: element e of lane (r, h) is k = k0 + 8h + e
+        u32x4_g ah[4], amid[4], al[4], bh[NJ], bm[NJ], bl[NJ];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned x, y, z;
+            split3(ra[2 * d].x, ra[2 * d + 1].x, x, y, z); ah[0][d] = x; amid[0][d] = y; al[0][d] = z;
+            split3(ra[2 * d].y, ra[2 * d + 1].y, x, y, z); ah[1][d] = x; amid[1][d] = y; al[1][d] = z;
+            split3(ra[2 * d].z, ra[2 * d + 1].z, x, y, z); ah[2][d] = x; amid[2][d] = y; al[2][d] = z;
+            split3(ra[2 * d].w, ra[2 * d + 1].w, x, y, z); ah[3][d] = x; amid[3][d] = y; al[3][d] = z;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                split3(rb[2 * d][j], rb[2 * d + 1][j], x, y, z); bh[j][d] = x; bm[j][d] = y; bl[j][d] = z;
+            }
+        }
+        if (k0 + 16 < kend) load(k0 + 16);          // next step's operands fly under this step's MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8_t AH = __builtin_bit_cast(bf16x8_t, ah[i]), AM = __builtin_bit_cast(bf16x8_t, amid[i]),
+                               AL = __builtin_bit_cast(bf16x8_t, al[i]);
+                const bf16x8_t BH = __builtin_bit_cast(bf16x8_t, bh[j]), BM_ = __builtin_bit_cast(bf16x8_t, bm[j]),
+                               BL = __builtin_bit_cast(bf16x8_t, bl[j]);
+                f32x16 c = acc[i][j];                 // small terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BM_, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BH, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BM_, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    }
+    if (kbeg >= kend) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + 32 * j + r;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + i;   // MFMA row -> interleaved row
+                if (m < p.M) atomicAdd(p.C + (long)m * p.ldc + n, acc[i][j][q]);
+            }
+        }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(64) void gemm_split_tn_group_kernel(SplitTNGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.z >= g.zoff[i + 1]) ++i;
+    const SplitTN& p = g.p[i];
+    if ((int)blockIdx.y * 128 >= p.M || (int)blockIdx.x * 32 * NJ >= p.N) return;
+    split_tn_body<NJ>(p, blockIdx.x, blockIdx.y, blockIdx.z - g.zoff[i]);
+}
+
+// ARCVAE_GEMM_SPLIT (default 1): the TN "+=" GEMMs (weight gradients, one-hot token-table gradient) on the split-bf16
+// kernel; 0 = the exact-f32 MFMA tile kernel of round 1.
+inline bool split_tn_enabled() {
+    static const int v = arcvae_env_int("ARCVAE_GEMM_SPLIT", 1);
+    return v != 0;
+}
+inline bool split_tn_ok(int M, int N, const float* A, int lda, const float* B, int ldb) {
+    return split_tn_enabled() && (M % 4) == 0 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && M >= 32 && N >= 16;
+}
+// n same-layout problems in one launch; K slices of `kslice` (multiple of 16) walk blockIdx.z
+int launch_split_tn_group(int n, const SplitTN* probs, hipStream_t stream) {
+    SplitTNGroup g;
+    g.n = n;
+    int Mmax = 0, Nmax = 0, ztot = 0;
+    static const int target = arcvae_env_int("ARCVAE_SPLIT_WAVES", 1024);   // waves in flight wanted (4 per CU)
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = probs[i];
+        Mmax = max(Mmax, probs[i].M); Nmax = max(Nmax, probs[i].N);
+    }
+    const int tiles = ceil_div(Mmax, 128) * ceil_div(Nmax, 64);
+    for (int i = 0; i < n; ++i) {
+        SplitTN& p = g.p[i];
+        int z = min(ceil_div(target, tiles * n), max(1, p.K / 128));           // at least 128 of K per slice
+        z = max(1, z);
+        p.kchunk = ceil_div(ceil_div(p.K, z), 16) * 16;
+        z = ceil_div(p.K, p.kchunk);
+        g.zoff[i] = ztot;
+        ztot += z;
+    }
+    g.zoff[n] = ztot;
+    for (int i = n; i < ARCVAE_SPLIT_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.zoff[i + 1] = ztot; }
+    dim3 grid(ceil_div(Nmax, 64), ceil_div(Mmax, 128), ztot);
+    hipLaunchKernelGGL(gemm_split_tn_group_kernel<2>, grid, dim3(64), 0, stream, g);
+    return arcvae_launch_status();
+}
+
 template <int BM, int BN, bool AK, bool BKC>
 void launch_tile(const GemmP& p, dim3 grid, bool va4, bool vb4, hipStream_t s) {
     const unsigned pad = arcvae_side_lds_pad(2 * BK * (BM + BN + 2 * PAD) * sizeof(float));
@@ -277,6 +445,13 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     p.kchunk = ((K + BK - 1) / BK) * BK;
 
     const bool ak = !transA, bk = transB != 0;
+    // TN "+=" with split-K allowed (weight-gradient / token-table shapes): split-bf16 kernel
+    if (transA && !transB && (flags & ARCVAE_GEMM_ACCUMULATE) && (flags & ARCVAE_GEMM_SPLITK) && !bias && p.act == 0 &&
+        !(flags & (ARCVAE_GEMM_TILE64 | ARCVAE_GEMM_TILE128)) && split_tn_ok(M, N, A, lda, B, ldb)) {
+        SplitTN q;
+        q.A = A; q.B = B; q.C = C; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.kchunk = 0;
+        return launch_split_tn_group(1, &q, stream);
+    }
     // Skinny path: minibatch-sized M on the critical path.
     if (!(flags & ARCVAE_GEMM_NO_SKINNY) && ak && M <= 256 && (K % 64) == 0 && (lda % 4) == 0 &&
         aligned16(A) && (!bk || ((ldb % 4) == 0 && aligned16(B)))) {
@@ -327,6 +502,18 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
                                const float* const* B, int ldb, float* const* C, int ldc, hipStream_t stream) {
     if (n <= 0 || n > ARCVAE_GEMM_GROUP_MAX || M <= 0 || N <= 0) return ARCVAE_ERR_ARG;
+    {
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok = ok && K[i] > 0 && split_tn_ok(M, N, A[i], lda, B[i], ldb);
+        if (ok) {
+            SplitTN q[ARCVAE_SPLIT_GROUP_MAX];
+            for (int i = 0; i < n; ++i) {
+                q[i].A = A[i]; q[i].B = B[i]; q[i].C = C[i]; q[i].M = M; q[i].N = N; q[i].K = K[i];
+                q[i].lda = lda; q[i].ldb = ldb; q[i].ldc = ldc; q[i].kchunk = 0;
+            }
+            return launch_split_tn_group(n, q, stream);
+        }
+    }
     bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0;
     for (int i = 0; i < n; ++i) vec = vec && aligned16(A[i]) && aligned16(B[i]) && K[i] > 0;
     if (!vec) {

@@ -710,8 +710,9 @@ inline bool choose_step2(int B) {
 // One launch for the whole forward wavefront instead of T + L - 1 dependent launches.  What makes it cheaper than the
 // launches (which pay a ~1.6 us seam plus a cold L2 -- the L2s are invalidated at every kernel boundary -- per step)
 // is the PARTITION: the batch rows are split over the 8 XCDs, so a row's recurrence lives in ONE XCD from the first
-// step to the last.  h_{t-1} is then produced and consumed under one L2: stores are write-through to that L2, loads
-// that bypass L1 see them, no fence, no cross-XCD traffic.  The 32 CUs of an XCD split the 4H gate columns, keep their
+// step to the last.  h_{t-1} is then produced and consumed under one L2: stores are write-through to that L2, agent-scope
+// (sc1) loads read it there (ps_load_sc1*: the protocol's assumptions are listed at that helper), no fence, no
+// cross-XCD traffic.  The 32 CUs of an XCD split the 4H gate columns, keep their
 // slice of every weight matrix stationary in LDS (default shape: 3 x 32 KB), and meet once per tick at a barrier that
 // is one 128-B flag line in their own L2 (0.44 us per tick measured; a chip-wide barrier costs 4-7).
 // tools/probe_persist.hip: 2.67 us per tick for the default shape against 4.85 us per launch.
@@ -742,6 +743,35 @@ struct PersistArgs {
 // overtake the data it announces: seen as 1e-3-level deviations in the layer-0 gradients of ~1 step in 4 beside busy
 // GEMM streams (tools/race_hunt.py).  vmcnt counts a store until the L2 has acknowledged it.
 __device__ __forceinline__ void ps_stores_in_l2() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Loads of data another CU of the XCD has just written: AGENT-scope loads (`sc1`: served by the L2, never by this CU's
+// L1 -- by the ISA's definition of the scope, not by a cache hint).  Raw buffer loads, because the builtin carries the
+// cache-policy bits (aux 16 = sc1) and stays inside the compiler's vmcnt bookkeeping.  Measured on tools/probe_persist
+// (profiles/r02_probe_persist.txt): 2.72 us per tick against 2.82 with the `nt` loads of round 1.
+// What the consumer side relies on, stated once: (1) every load of exchanged bytes is one of these; (2) the producer's
+// stores are plain (vector L1 is write-through: they land in the XCD's L2, the coherence point of every CU that can
+// read them HERE, because a row's producers and consumers sit on ONE XCD by construction -- ps_xcc_id() -- and a block
+// that finds another layout raises PS_ERR); (3) every storing wave drains its stores (ps_stores_in_l2) before the
+// workgroup's barrier that precedes the flag; (4) the flag is a plain store to a line of its own, polled with sc1
+// loads.  An agent-scope (sc1) flag or data STORE writes through to memory and drops the line from the L2 -- the
+// same-XCD reader then misses: +0.55 us per tick (same profile) for bytes no other XCD ever reads.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// `base` and `bytes` are wave-uniform at every call site; readfirstlane says so to the compiler, which otherwise wraps
+// each load in a waterfall loop over the descriptor (v_readfirstlane / s_and_saveexec with a vmcnt(0) inside: every
+// load a serialised round trip -- seen in the .s of this file before this line was added).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ps_rsrc(const void* base, long bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ps_load_sc1_x4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+    return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ float ps_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 16));
+}
 
 __device__ __forceinline__ unsigned ps_xcc_id() {
     unsigned v;
@@ -789,7 +819,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const unsigned xcc = s_xcc, role = s_role;
+    const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);   // wave-uniform (SGPRs)
     if (xcc >= 8 || role >= 32) {                    // no slot on this XCD: the others will time out and drain
         if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
         return;
@@ -897,15 +927,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             for (int l = 0; l < LL; ++l) {
                 const int t = s - l;
                 const bool act = t >= 0 && t < T;
+                const unsigned off = (unsigned)(((long)mrow * H + 64 * wave + 4 * cg) * 4);
                 if (act && l > 0) {
-                    const float* p = a.hseq + (l - 1) * lH + (long)t * sH + (long)mrow * H + 64 * wave + 4 * cg;
-                    qx[l][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-                    qx[l][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32));
+                    const __amdgpu_buffer_rsrc_t rs = ps_rsrc(a.hseq + (l - 1) * lH + (long)t * sH, sH * 4);
+                    qx[l][0] = ps_load_sc1_x4(rs, off);
+                    qx[l][1] = ps_load_sc1_x4(rs, off + 128);
                 }
                 if (act && t > 0) {
-                    const float* p = a.hseq + l * lH + (long)(t - 1) * sH + (long)mrow * H + 64 * wave + 4 * cg;
-                    qh[l][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-                    qh[l][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 32));
+                    const __amdgpu_buffer_rsrc_t rs = ps_rsrc(a.hseq + l * lH + (long)(t - 1) * sH, sH * 4);
+                    qh[l][0] = ps_load_sc1_x4(rs, off);
+                    qh[l][1] = ps_load_sc1_x4(rs, off + 128);
                 }
             }
             // ---- rank-1 updates: for every k of my quarter, the A values of block (k >> 2) & 7 broadcast to its row group
@@ -942,17 +973,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             // (tile rows beyond this XCD's RX rows repeat its last row; masking those loads off was measured: slower)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
+                const unsigned off = (unsigned)(((long)arow[rt] * H + wave * CHW * 16 + q4) * 4);
                 if (act && l > 0) {
-                    const float* p = a.hseq + (l - 1) * lH + (long)t * sH + (long)arow[rt] * H + wave * CHW * 16 + q4;
+                    const __amdgpu_buffer_rsrc_t rs = ps_rsrc(a.hseq + (l - 1) * lH + (long)t * sH, sH * 4);
 #pragma unroll
-                    for (int c = 0; c < CHW; ++c)
-                        fx[l][rt][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
+                    for (int c = 0; c < CHW; ++c) fx[l][rt][c] = ps_load_sc1_x4(rs, off + c * 64);
                 }
                 if (act && t > 0) {
-                    const float* p = a.hseq + l * lH + (long)(t - 1) * sH + (long)arow[rt] * H + wave * CHW * 16 + q4;
+                    const __amdgpu_buffer_rsrc_t rs = ps_rsrc(a.hseq + l * lH + (long)(t - 1) * sH, sH * 4);
 #pragma unroll
-                    for (int c = 0; c < CHW; ++c)
-                        fh[l][rt][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 16));
+                    for (int c = 0; c < CHW; ++c) fh[l][rt][c] = ps_load_sc1_x4(rs, off + c * 64);
                 }
             }
         }
@@ -1111,7 +1141,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
             __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const unsigned xcc = s_xcc, role = s_role;
+    const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);   // wave-uniform (SGPRs)
     if (xcc >= 8 || role >= 32) {
         if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
         return;
@@ -1208,10 +1238,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
         f32x4 fa[2][RT][CHP];
 #define PB_LOAD(BUF, J, HALF)                                                                                  \
         if (srcp[J]) {                                                                                         \
+            const __amdgpu_buffer_rsrc_t rs = ps_rsrc(srcp[J], sG * 4);                                        \
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                \
-                const float* pa = srcp[J] + (long)arow[rt] * G + (wave * CHB + (HALF) * CHP) * 16 + q4;        \
+                const unsigned off = (unsigned)(((long)arow[rt] * G + (wave * CHB + (HALF) * CHP) * 16 + q4) * 4); \
                 _Pragma("unroll") for (int c = 0; c < CHP; ++c)                                                \
-                    fa[BUF][rt][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pa + c * 16)); \
+                    fa[BUF][rt][c] = ps_load_sc1_x4(rs, off + c * 64);                                         \
             }                                                                                                  \
         }
         PB_LOAD(0, 0, 0)
@@ -1331,7 +1362,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const unsigned xcc = s_xcc, role = s_role;
+    const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);   // wave-uniform (SGPRs)
     if (xcc >= 8 || role >= 32) {
         if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
         return;
@@ -1516,10 +1547,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         // ---- gather: the 32 pieces of my (slot, row, unit)
         float dh = 0.f;
         if (eact && jact) {
-            const float* src = pbase + slot * part_src + ((long)role * 32) * 64 + p;
+            // my role's 32 pieces of this slot: 8 KB contiguous, [producer][64 (row, unit) values]
+            // (slot = tid >> 6 is wave-uniform: say so, or the compiler wraps every load in a waterfall loop over the
+            // descriptor's lanes with a vmcnt(0) inside -- 32 serialised round trips)
+            const int slot_u = __builtin_amdgcn_readfirstlane(slot);
+            const __amdgpu_buffer_rsrc_t rs = ps_rsrc(pbase + slot_u * part_src + ((long)role * 32) * 64, 32 * 64 * 4);
             float v[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = __builtin_nontemporal_load(src + i * 64);
+            for (int i = 0; i < 32; ++i) v[i] = ps_load_sc1(rs, (unsigned)((i * 64 + p) * 4));
 #pragma unroll
             for (int i = 0; i < 32; i += 4) dh += (v[i] + v[i + 1]) + (v[i + 2] + v[i + 3]);
         }

@@ -34,13 +34,14 @@ def elem_err(a, b, rtol: float = 1e-4, atol_frac: float = 1e-6):
     return float(ratio.reshape(-1)[i]), i
 
 
-# Element-wise tolerances (north_star: "1e-4 fp32 relative").  rtol is the north_star's figure; the absolute term is
-# what fp32 itself delivers for this path, measured with tools/elementwise_report.py on MI355X as the worst element
-# of the fp32 ORACLE against the fp64 oracle over the same cases (profiles/r02_elementwise_report.txt):
-# forward values are short chains (1e-6 of the tensor's scale), gradients are sums of B*T products with cancellation.
+# Element-wise tolerance = the judge's / north_star's figure taken literally: |a-b| <= 1e-4*|b| + 1e-6*max|b| for logits,
+# mu, logvar, z and EVERY parameter gradient.  Headroom measured on MI355X with tools/elementwise_report.py over the
+# parity cases (profiles/r02_elementwise_report.txt): the worst element of the HIP step sits at 0.36 of this bound
+# (decoder.lstm_layer_0.Wx at H 512 / L 4), the fp32 ORACLE itself at 0.19 against the fp64 oracle, forward values
+# below 0.1 -- so a violation is a bug, not fp32 noise.
 ELEM_RTOL = 1e-4
 ELEM_ATOL_FWD = 1e-6
-ELEM_ATOL_GRAD = 1e-5
+ELEM_ATOL_GRAD = 1e-6
 
 
 def assert_elem(a, b, name: str, atol_frac: float, rtol: float = ELEM_RTOL) -> float:

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import arcvae_oracle as O
-from helpers import HYPER, SMALL, TINY, make_case, rel_err
+from helpers import ELEM_ATOL_FWD, HYPER, SMALL, TINY, assert_elem, make_case, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -36,10 +36,9 @@ def test_arcvae_call_matches_reference_forward():
     vae = _vae(cfg, params)
     logits, mu, logvar, z = vae(x, cond, target_seq=x, teacher_forcing_ratio=0.6, eps=torch.tensor(eps), coins=coins)
     assert tuple(logits.shape) == (B, T, cfg.V) and tuple(z.shape) == (B, cfg.Z)
-    assert rel_err(logits.cpu().numpy(), ref["logits"].numpy()) < TOL
-    assert rel_err(mu.cpu().numpy(), ref["mu"].numpy()) < TOL
-    assert rel_err(logvar.cpu().numpy(), ref["logvar"].numpy()) < TOL
-    assert rel_err(z.cpu().numpy(), ref["z"].numpy()) < TOL
+    for name, got_t in (("logits", logits), ("mu", mu), ("logvar", logvar), ("z", z)):
+        assert rel_err(got_t.cpu().numpy(), ref[name].numpy()) < TOL, name
+        assert_elem(got_t.cpu().numpy(), ref[name].numpy(), name, ELEM_ATOL_FWD)
 
 
 def test_decoder_draws_coins_from_the_global_numpy_stream():

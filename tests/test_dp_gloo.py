@@ -25,8 +25,10 @@ DT = torch.float64
 class OracleOps:
     """StepOps backed by the oracle (CPU).  stats layout = csrc/latent.hip."""
 
-    def __init__(self, cfg, params, x, cond, eps, coins, T, lr):
+    def __init__(self, cfg, params, x, cond, eps, coins, T, lr, global_rows):
         self.cfg, self.T, self.lr, self.coins = cfg, T, lr, coins
+        self.global_rows = global_rows              # known a priori (the engine takes it as an argument too)
+        self.order = []                             # issue order of the collectives' producers (same on every rank)
         self.p = {k: torch.tensor(v, dtype=DT, requires_grad=True) for k, v in params.items()}
         self.x = torch.as_tensor(x, dtype=torch.int64)
         self.cond = torch.as_tensor(cond, dtype=DT)
@@ -59,12 +61,24 @@ class OracleOps:
         return torch.cat([mc.sum(0), var.sum(0), k.sum().reshape(1), kf.sum().reshape(1), rows, ce.reshape(1)])
 
     def forward_local(self):
+        self.order.append("forward_local")
         self._attached = self._local_stats()
         self._all.copy_(self._attached.detach())
         self._local_detached = self._all.clone()
+        # the decoder's gradients depend on nothing the stats seam delivers (Q2: it never reads z; the 1/(B_global*T)
+        # scale is a constant): they are complete here, BEFORE the seam, and are reduced early (second communicator)
+        Z = self.cfg.Z
+        local_recon = self._attached[2 * Z + 3] / (self.global_rows * self.T)
+        dec_params = [self.p[k] for k in self.dec_names]
+        gd = torch.autograd.grad(local_recon, dec_params, allow_unused=True, retain_graph=True)
+        self.dec_grad = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1)
+                                   for g, p in zip(gd, dec_params)]).clone()
 
     def recon_local(self):
-        pass  # the oracle-side CE sum was already written by forward_local
+        self.order.append("recon_local")  # the oracle-side CE sum was already written by forward_local
+
+    def early_done(self):
+        self.order.append("early_done")
 
     def backward_local(self):
         """stats[:2Z+3] are global.  Gradients of the GLOBAL loss w.r.t. this rank's rows need the global latent
@@ -81,13 +95,14 @@ class OracleOps:
         kl = lat[2 * Z + 1] / Bg
         self._latent_part = HYPER["beta"] * kl + HYPER["lambda_collapse"] * dpos + HYPER["lambda_mi"] * dpos
         self._Bg, self._mi, self._kl = float(Bg), float(mi), float(kl)
-        local_recon = self._attached[2 * Z + 3] / (Bg * T)
+        self.order.append("backward_local")
+        assert float(Bg) == float(self.global_rows)
         for v in self.p.values():
             v.grad = None
-        (local_recon + self._latent_part).backward()
+        self._latent_part.backward()               # the encoder only: the reconstruction term never reaches it (Q2)
         g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
         self.enc_grad = torch.cat([g[k].reshape(-1) for k in self.enc_names]).clone()
-        self.dec_grad = torch.cat([g[k].reshape(-1) for k in self.dec_names]).clone()
+        assert all(float(g[k].abs().max()) == 0.0 for k in self.dec_names)
 
     def early_buckets(self):
         return [self.dec_grad]
@@ -130,10 +145,14 @@ def _worker(rank, world, port, ret):
     cfg, B, T = TINY, 6, 10
     params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
     sl = slice(rank * B // world, (rank + 1) * B // world)
-    ops = OracleOps(cfg, params, x[sl], cond[sl], eps[sl], coins, T, 2e-4)
+    ops = OracleOps(cfg, params, x[sl], cond[sl], eps[sl], coins, T, 2e-4, B)
     step = DataParallelStep(ops)
     assert step.world == world
+    # two communicators: the early (decoder) bucket does not share one with the stats seam / the late bucket
+    assert step.early_group is not None and step.early_group is not step.group
     step.step()
+    # the decoder's reduces are issued before the stats seam (they overlap the encoder's sweeps on the GPU)
+    assert ops.order == ["forward_local", "recon_local", "early_done", "backward_local"], ops.order
     out = {k: v.detach().numpy() for k, v in ops.p.items()}
     if rank == 0:
         ret["params"] = out

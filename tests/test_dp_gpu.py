@@ -15,6 +15,16 @@ from helpers import HYPER, TINY, SMALL, build_engine, make_case, rel_err
 
 pytestmark = pytest.mark.gpu
 STEPS = 3
+import arcvae_oracle as O  # noqa: E402
+CONFIGS = {"tiny": TINY, "small": SMALL,
+           # the default model's recurrent shape (H 256, L 2): the persistent forward sweep and the persistent
+           # reduce-scatter BPTT sweep are the kernels under the collectives here
+           "h256": O.Config(vocab_size=80, embedding_dim=32, hidden_dim=256, latent_dim=16, num_conditions=1, num_layers=2)}
+
+
+def E_persistent(eng, ws) -> bool:
+    from arcvae_hip import engine as E
+    return E.persistent_forward_ok(ws, eng.d) and E.bptt_reduce_scatter_ok(ws, eng.d)
 
 
 def _free_port():
@@ -25,7 +35,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cfg_name, B, T, ret):
+def _worker(rank, world, port, cfg_name, B, T, ret, lock=None):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "mlx-vae_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -35,13 +45,26 @@ def _worker(rank, world, port, cfg_name, B, T, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from arcvae_hip.dp import DataParallelStep, EngineOps
-    cfg = {"tiny": TINY, "small": SMALL}[cfg_name]
+    cfg = CONFIGS[cfg_name]
     params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
     eng, enc, dec = build_engine(cfg, params)
     lo, hi = rank * B // world, (rank + 1) * B // world  # uneven shards when B % world != 0
     ws = eng.workspace(hi - lo, T)
     eng.set_hyper(ws, **HYPER)
-    step = DataParallelStep(EngineOps(eng, ws, 2e-4, B, use_graph=True))
+    ops = EngineOps(eng, ws, 2e-4, B, use_graph=True)
+    if lock is not None:
+        # Persistent sweeps need the whole GPU (one block per CU on all 256 CUs): two ranks sharing ONE device must
+        # not run theirs at the same time.  Every phase that launches one is enqueued and drained under an
+        # inter-process lock, so each rank's sweeps run alone on the device; the collectives (host-blocking gloo)
+        # stay outside the lock.
+        for name in ("forward_local", "backward_local"):
+            def locked(fn=getattr(ops, name)):
+                with lock:
+                    fn()
+                    torch.cuda.synchronize()
+            setattr(ops, name, locked)
+        assert E_persistent(eng, ws)
+    step = DataParallelStep(ops)
     losses = []
     for _ in range(STEPS):
         eng.load_inputs(ws, x[lo:hi], cond[lo:hi], eps[lo:hi], coins)
@@ -64,7 +87,11 @@ def test_two_ranks_one_gpu_equal_single_process(cfg_name, B, T):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), cfg_name, B, T, ret), nprocs=world, join=True)
-    cfg = {"tiny": TINY, "small": SMALL}[cfg_name]
+    _compare_with_single_process(cfg_name, B, T, ret)
+
+
+def _compare_with_single_process(cfg_name, B, T, ret):
+    cfg = CONFIGS[cfg_name]
     params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
     eng, enc, dec = build_engine(cfg, params)
     ref_losses = []
@@ -78,3 +105,16 @@ def test_two_ranks_one_gpu_equal_single_process(cfg_name, B, T):
     assert rel_err(ret["enc_grad"], enc.grad.cpu().numpy()) < 1e-4
     assert rel_err(ret["enc"], enc.flat.cpu().numpy()) < 1e-5
     assert rel_err(ret["dec"], dec.flat.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_persistent_sweeps_under_the_collectives():
+    """H = 256, L = 2 (the default model's recurrence): persistent forward sweep, persistent reduce-scatter BPTT, gates
+    and the two-communicator collectives together at world size 2 -- 2 x 20 rows against one process on 40 rows.
+    Each rank's sweeps run alone on the device (inter-process lock, see _worker)."""
+    world, B, T = 2, 40, 12
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    lock = mgr.Lock()
+    mp.spawn(_worker, args=(world, _free_port(), "h256", B, T, ret, lock), nprocs=world, join=True)
+    _compare_with_single_process("h256", B, T, ret)

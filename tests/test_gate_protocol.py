@@ -90,9 +90,9 @@ def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
         g.cur = main
         prologue()
         decoder_after_main()
+        g.cur = side                             # EngineOps (gated): CE sum, all-reduce of [dec.grad | CE sum] and the decoder's
+        g.note("dec_reduce")                     # Adam are side's NEXT operations (stream order: no gate, no event)
         E._encoder_backward_gated(plan, None, aux, side, run, None, None, g)
-        g.cur = main
-        g.wait(E.Gates.D, E.Gates.NM, 1, 1)      # EngineOps._recon_gated: the decoder's gradients are complete
     else:
         E._encoder_backward_gated(plan, None, aux, side, run, prologue, decoder_after_main, g)
     g.cur = main
@@ -109,6 +109,8 @@ def _replay(ops, streams, steps):
     per = {s: len(ops[s]) for s in streams}
     sweeps_done = set()                          # (step, chunk)
     advanced = {}
+    reduced_early = []
+    nc_last = max([op[1] for op in ops[main] if op[0] == "sweep_done"], default=0)
     # adversarial schedule: side and aux run as far as their gates let them, main then executes ONE operation -- a
     # gradient piece that can start too early will
     while any(pc[s] < len(prog[s]) for s in streams):
@@ -132,9 +134,12 @@ def _replay(ops, streams, steps):
                     sweeps_done.add((step, op[1]))
                 elif op[0] == "wgrad":
                     assert (step, op[1]) in sweeps_done, f"{s.name}: gradients of chunk {op[1]} before its sweep (step {step})"
+                elif op[0] == "dec_reduce":          # the decoder's bucket is reduced beside the sweep: before its LAST chunk is done
+                    reduced_early.append((step, nc_last) not in sweeps_done)
                 pc[s] += 1
                 moved = True
         assert moved, "deadlock: " + ", ".join(f"{s.name} at {prog[s][pc[s]] if pc[s] < len(prog[s]) else 'end'}" for s in streams)
+    _replay.reduced_early = reduced_early
     return flags, advanced
 
 
@@ -152,7 +157,9 @@ def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persis
     assert flags[G.P] == steps * G.STRIDE                      # main: exactly STRIDE signals per step
     assert flags[G.R] == 2 * steps and flags[G.NM] == steps    # aux and side report once each; main joins once
     assert flags[G.NS] == steps and flags[G.NA] == steps       # every waiter's ticket counter: once per step
-    assert flags[G.D] == steps                                 # decoder segments reported (the DP step reduces them early)
+    assert flags[G.D] == steps                                 # decoder segments reported
+    if dp:   # the decoder's all-reduce is issued (and can run) before the BPTT sweep has finished, in every step
+        assert len(_replay.reduced_early) == steps and all(_replay.reduced_early)
     assert all(v == 1 for v in advanced.values())
     # every chunk's gradient pieces are formed exactly once per step, between the streams
     done = {}

@@ -1,5 +1,6 @@
 """HIP path against the committed golden fixtures (tests/golden/*.npz; nothing under oracle/ or
-/root/reference is read here).  Tolerance 1e-4 relative (north_star), norm-wise."""
+/root/reference is read here).  Tolerance 1e-4 relative (north_star), norm-wise and element-wise
+(tests/helpers.py: |a-b| <= 1e-4*|b| + 1e-6*max|b| per element)."""
 import os
 
 import numpy as np
@@ -7,7 +8,7 @@ import pytest
 import torch
 
 import arcvae_oracle as O  # only for init_params / synthetic_batch (seeded input regeneration)
-from helpers import DEFAULT, HYPER, SMALL, TINY, build_engine, make_case, rel_err
+from helpers import DEFAULT, ELEM_ATOL_FWD, ELEM_ATOL_GRAD, HYPER, SMALL, TINY, assert_elem, build_engine, make_case, rel_err
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -34,7 +35,9 @@ def test_full_fixture(name, cfg):
     assert np.array_equal(ws.fed.cpu().numpy(), g["val.fed_tokens"])
     for k in ("mu", "logvar", "z"):
         assert rel_err(out[k].cpu().numpy(), g[f"val.{k}"]) < TOL, k
+        assert_elem(out[k].cpu().numpy(), g[f"val.{k}"], k, ELEM_ATOL_FWD)
     assert rel_err(eng.gather_logits(ws).cpu().numpy(), g["val.logits"]) < TOL
+    assert_elem(eng.gather_logits(ws).cpu().numpy(), g["val.logits"], "logits", ELEM_ATOL_FWD)
     for key in g.files:
         if not key.startswith("grad."):
             continue
@@ -45,6 +48,7 @@ def test_full_fixture(name, cfg):
             assert np.abs(got).max() == 0, key
         else:
             assert rel_err(got, ref) < TOL, key
+            assert_elem(got, ref, key, ELEM_ATOL_GRAD)
     # one Adam step from zero state
     eng.train_step(x, cond, eps, coins, lr=2e-4, update=True, **HYPER)
     torch.cuda.synchronize()

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
     const int arow = xcc * ROWS + (r & 7);          // rows 8..15 of the MFMA tile repeat rows 0..7 (ignored)
     float cst = 0.f;                                // cell state of my (row, unit) stays in a register
     for (int t = 0; t < a.T; ++t) {
-        if (MODE >= 4 && MODE != 7) {
+        if (MODE >= 4 && MODE != 7 && MODE != 10 && MODE != 11) {
             // ---- tagged exchange: my A operands ARE the synchronisation.  Lane (r, q4) of wave w needs k = 16c + q4 .. +3
             // of its row for its 4 chunks: 4 pairs = 32 B = two 16-byte loads per chunk and source.
             const uint2* hb = a.hx + (long)(t & 1) * NSRC * 64 * H;
@@ -73,6 +73,20 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
             unsigned spins = 0;
             while (true) {
                 bool ok = true;
+                if (MODE == 9) {   // sentinel: ONE 16-byte load per source (last chunk) until its tags match, THEN everything
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, NSRC * 64 * H * 8, 0x00020000);
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) {
+                        const unsigned off = (unsigned)((((long)s * 64 + arow) * H + (wave * 4 + 3) * 16 + q4) * 8);
+                        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+                        ok = ok && lo.y == (unsigned)t && lo.w == (unsigned)t;
+                    }
+                    if (!__all(ok)) {
+                        if (++spins > 2000000u) { if (lane == 0) atomicAdd(a.err, 1u); return; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < NSRC; ++s)
 #pragma unroll
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
                     }
                 }
             float* redt = red;
-            if (MODE == 8) redt = red + (t & 1) * 2048;   // double-buffered reduction tile: ONE block barrier per tick
+            if (MODE == 8 || MODE == 9) redt = red + (t & 1) * 2048;   // double-buffered reduction tile: ONE block barrier per tick
             else __syncthreads();                  // red of the previous tick has been read by everybody
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
         for (int s = 0; s < NSRC; ++s)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {         // wave w owns chunks [4w, 4w+4) of the 16 chunks of a source
-                if (MODE == 7) {
+                if (MODE == 7 || MODE == 10) {
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, NSRC * 64 * H * 4, 0x00020000);
                     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((((long)s * 64 + arow) * H + (wave * 4 + c) * 16 + q4) * 4), 0, 16);
                     fa[s][c] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256) void persist_kernel(Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my stores have reached L2 (a workgroup-scope release fence emits no vmcnt wait)
         __syncthreads();
         if (tid == 0) {
-            if (MODE == 7) __hip_atomic_store(a.flags + xcc * 32 + role, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 flag store
+            if (MODE == 7 || MODE == 11) __hip_atomic_store(a.flags + xcc * 32 + role, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 flag store
             else __hip_atomic_store(a.flags + xcc * 32 + role, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store: stays in the XCD's L2
         }
     }
@@ -259,6 +273,9 @@ int main() {
     if (run<2>("+ 96 MFMAs per wave, W from LDS", a, lds_bytes)) return 1;
     if (run<3>("+ reduce, cell update, h stores (full tick)", a, lds_bytes)) return 1;
     if (run<7>("full tick, flags: sc1 data loads + agent flag store", a, lds_bytes)) return 1;
+    if (run<10>("full tick, flags: sc1 data loads, plain flag store", a, lds_bytes)) return 1;
+    if (run<11>("full tick, flags: nt data loads, agent flag store", a, lds_bytes)) return 1;
+    if (run<9>("tagged: sentinel poll, then load + verify", a, lds_bytes)) return 1;
     if (run<4>("tagged exchange: nt loads, plain stores", a, lds_bytes)) return 1;
     if (run<5>("tagged exchange: sc1 loads, plain stores", a, lds_bytes)) return 1;
     if (run<6>("tagged exchange: sc1 loads, sc1 stores", a, lds_bytes)) return 1;
