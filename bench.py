@@ -495,16 +495,11 @@ def roofline_probe(eng, ws, torch):
     reps = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     persistent = E.bptt_reduce_scatter_ok(ws, d)   # the BPTT sweep of this shape is ONE persistent launch per chunk
+    plan = E.EncoderBackwardPlan(eng.enc, ws, d)
+    fused = bool(getattr(plan, "fused", False))    # ... which also forms the stack's weight gradients (FW variant)
 
-    def sweep():
-        if persistent:   # the whole sweep as one launch of lstm_bwd_persist_rs_kernel: `launches` ticks
-            E.call("arcvae_enc_lstm_backward_persistent_rs", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb),
-                   2 * d.H, E.ptr(ws.dG), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.ppart), E.ptr(ws.psync), None, B, Tn,
-                   d.H, d.L, 0, launches, 0, None, E.stream_ptr())
-            return
-        E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * d.H,
-               E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, Tn, d.H, d.L, 0, launches,
-               1, None, None, E.stream_ptr())
+    def sweep():   # the whole sweep through the engine's own call: persistent (one launch of `launches` ticks) or launches
+        plan.sweep(0, launches, None, 0)
 
     sweep()
     torch.cuda.synchronize()
@@ -531,7 +526,9 @@ def roofline_probe(eng, ws, torch):
         e1.record(s)
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / reps / launches
-    flops_total = 2.0 * B * 4 * d.H * d.H * (d.L * (Tn - 1) + (d.L - 1) * Tn)
+    flops_total = 2.0 * B * 4 * d.H * d.H * (d.L * (Tn - 1) + (d.L - 1) * Tn)   # dh = dG.Wh and dX = dG.Wx contractions
+    if fused:
+        flops_total *= 2.0    # + dWh_l += dG_l^T.h_l[t-1] (L(T-1) of them) and dWx_l += dG_l^T.h_{l-1}[t] ((L-1)T): same count
     ach = flops_total / launches / (us * 1e-6) / 1e12
     kernel = "lstm_bwd_persist_rs_kernel" if persistent else "lstm_bwd_step_kernel"
     # traffic: fabric-side bytes per tick / launch from the newest committed rocprofv3 --pmc summary (separate passes,
@@ -559,9 +556,13 @@ def roofline_probe(eng, ws, torch):
         except Exception:
             tick_model = None
     if persistent:
-        note = ("dominant kernel: the persistent BPTT sweep (lstm_bwd_persist_rs_kernel, one launch per chunk; DESIGN.md "
-                "section 6b); a 'launch' here is one TICK of it (same 2L-1 contractions as a launch of the per-step "
-                "kernel it replaced).  achieved = isolated sweep as ONE launch (HIP events on its stream) / ticks; "
+        note = (("dominant kernel: the persistent BPTT sweep with the stack's weight gradients formed inside it "
+                 "(lstm_bwd_persist_rs_kernel, FW variant: ONE launch per step; DESIGN.md section 6d); a 'launch' here is "
+                 "one TICK of it: the 2L-1 contractions of the per-step kernel it replaced PLUS the 2L-1 weight-gradient "
+                 "outer products of the same tick." if fused else
+                 "dominant kernel: the persistent BPTT sweep (lstm_bwd_persist_rs_kernel, one launch per chunk; DESIGN.md "
+                 "section 6b); a 'launch' here is one TICK of it (same 2L-1 contractions as a launch of the per-step "
+                 "kernel it replaced).") + "  achieved = isolated sweep as ONE launch (HIP events on its stream) / ticks; "
                 "in_step_* = tick cadence inside the last timed step (device-side stamps, weight-gradient GEMMs beside it). "
                 "`bound` names the section-8(d) denominator (f32-input MFMA peak, exact-f32 path); the LIMITER is the "
                 "tick latency of a 259-tick dependent chain (exchange through the XCD's L2, block barriers, epilogue), "

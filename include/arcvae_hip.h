@@ -112,6 +112,17 @@ int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* 
                                            float* dxs, float* part_ws, unsigned* sync_ws, unsigned* start_signal, int B,
                                            int T, int H, int L, int s_begin, int s_end, int chunk_index,
                                            unsigned long long* trace, arcvae_stream_t stream);
+/* The reduce-scatter sweep with the stack's weight gradients formed INSIDE the kernel: replaces
+ * arcvae_enc_lstm_backward_persistent_rs + the per-layer GEMMs / bias sums / token segment-sum of arcvae_enc_lstm_wgrad
+ * for the same ticks.  "+=" into dWh[l], dWx[l] (l >= 1), dbias[l] (l >= 1); the layer-0 input side arrives as
+ * dtable_ws [V,4H] (zeroed by the chunk_index == 0 call) for arcvae_table_finalize.  hseq [L,T,B,H] and x_tb [T,B] as
+ * written / read by the forward sweep; dWx, dWh, dbias: HOST arrays of device pointers.  Same shape rule as _rs. */
+int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* Wh, const float* cseq, const float* gseq,
+                                   const float* hseq, const int32_t* x_tb, const float* dh_top, int ld_dh_top,
+                                   float* dG, float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
+                                   unsigned* start_signal, float* const* dWx, float* const* dWh, float* const* dbias,
+                                   float* dtable_ws, int B, int T, int V, int H, int L, int s_begin, int s_end,
+                                   int chunk_index, unsigned long long* trace, arcvae_stream_t stream);
 /* (the sweep is T+2(L-1) dependent launches; [s_begin, s_end) selects a sub-range so the caller can interleave
  *  events: after launches [0, s_end) every layer has finished all t >= T - s_end + 2(L-1).)
  * Parameter gradients of the stack from dG over time range [t_lo, t_hi): embedding.weight,

@@ -39,6 +39,8 @@ SIGNATURES = {
     "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_rs_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_lstm_backward_fused": [_pp, _pp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _vp,
+                                       _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _vp],

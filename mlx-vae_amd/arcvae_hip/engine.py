@@ -147,6 +147,14 @@ def bptt_reduce_scatter_ok(ws, d: ModelDims) -> bool:
     return _lib.load().arcvae_enc_lstm_bwd_rs_ok(ws.B, ws.T, d.H, d.L) == 1
 
 
+def fused_wgrad_ok(ws, d: ModelDims) -> bool:
+    """ARCVAE_FUSED_WGRAD=1 (opt-in): the BPTT sweep of this shape forms the stack's weight gradients itself (FW variant of
+    lstm_bwd_persist_rs_kernel: no weight-gradient GEMMs, no chunks).  Parity-green, but measured SLOWER than the sweep +
+    GEMMs on aux / side (the tick grows from 2.8 to 4.7 us -- nothing added to the chain's wave
+    hides -- which costs 240 us per step against the 220 us the separate GEMMs cost), so it is not the default."""
+    return os.environ.get("ARCVAE_FUSED_WGRAD", "0") == "1" and bptt_reduce_scatter_ok(ws, d)
+
+
 def persistent_forward_ok(ws: Workspace, d: ModelDims) -> bool:
     """The forward sweep of this shape can run as one persistent launch (csrc/lstm.hip: lstm_fwd_persist_kernel)."""
     return _lib.load().arcvae_enc_lstm_persistent_ok(ws.B, ws.T, d.H, d.L) == 1
@@ -341,13 +349,15 @@ class EncoderBackwardPlan:
     # dWx GEMMs on side 1.060 / 1.040-1.044 / 1.037 / 1.045 / 1.051).
     FRACTIONS_LAUNCHES = "0.3,0.6,0.85,1.0"
     FRACTIONS_PERSISTENT = "0.63,1.0"
+    FRACTIONS_FUSED = "1.0"      # weight gradients formed inside the sweep: one launch, nothing to hand over
 
     def __init__(self, enc: ParamStore, ws: Workspace, d: ModelDims):
         self.enc, self.ws, self.d = enc, ws, d
         L, T = d.L, ws.T
         self.persistent = bptt_reduce_scatter_ok(ws, d)
-        self.FRACTIONS = tuple(float(f) for f in os.environ.get(
-            "ARCVAE_BPTT_CHUNKS", self.FRACTIONS_PERSISTENT if self.persistent else self.FRACTIONS_LAUNCHES).split(","))
+        self.fused = fused_wgrad_ok(ws, d)
+        default = self.FRACTIONS_FUSED if self.fused else (self.FRACTIONS_PERSISTENT if self.persistent else self.FRACTIONS_LAUNCHES)
+        self.FRACTIONS = tuple(float(f) for f in os.environ.get("ARCVAE_BPTT_CHUNKS", default).split(","))
         self.S = T + 2 * (L - 1)  # launches of the BPTT wavefront (csrc/lstm.hip)
         self._wx = _layer_ptrs(enc, L, "Wx", skip0=True)
         self._wh = _layer_ptrs(enc, L, "Wh")
@@ -387,6 +397,14 @@ class EncoderBackwardPlan:
         # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
         sig = start_signal if start_signal is not None else C.c_void_p(0)
+        if self.fused:
+            # default shape: the reduce-scatter sweep with the weight gradients formed inside it
+            enc = self.enc
+            call("arcvae_enc_lstm_backward_fused", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.hseq),
+                 ptr(ws.x_tb), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), ptr(ws.psync),
+                 sig, self._dwx[0], self._dwh[0], self._dbs[0], ptr(ws.dtable0), ws.B, ws.T, d.V, d.H, d.L, s0, s1,
+                 chunk_index, ptr(ws.trace_bwd), stream_ptr())
+            return
         if self.persistent:
             # latency regime, default shape: persistent BPTT sweep in its reduce-scatter form, one launch per chunk
             # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
@@ -407,6 +425,16 @@ class EncoderBackwardPlan:
 
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3) -> None:
         enc, ws, d = self.enc, self.ws, self.d
+        if os.environ.get("ARCVAE_DEBUG_SKIP_WGRAD", "0") == "1":   # timing experiments only (gradients are WRONG)
+            return
+        if self.fused:
+            # the sweep has formed dWh_l, dWx_l, dbias_l (l >= 1) and the token table itself; what is left is folding the
+            # table into embedding.weight / lstm_layer_0.{Wx,bias} once the last chunk is done
+            if last and (parts & 2):
+                call("arcvae_table_finalize", ptr(ws.dtable0), ptr(enc.p("lstm_layer_0.Wx")), d.E,
+                     ptr(enc.p("embedding.weight")), ptr(enc.g("embedding.weight")), ptr(enc.g("lstm_layer_0.Wx")),
+                     ptr(enc.g("lstm_layer_0.bias")), d.V, d.E, 4 * d.H, stream_ptr())
+            return
         call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
              ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(ws.onehot), ptr(enc.g("embedding.weight")), self._dwx[0],
              self._dwh[0],
@@ -480,6 +508,9 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     nc = len(plan.chunks)
     if nc + 1 > g.STRIDE:
         raise ValueError("too many BPTT chunks for the gate stride")
+    if getattr(plan, "fused", False) and nc == 1 and aux2 is not None:
+        _encoder_backward_gated_fused(plan, ws, aux, aux2, run, prologue, after_first, g)
+        return
     tail_on_side = aux2 is not None and nc >= 2
     # Since the persistent sweeps the weight-gradient stream, not the chain, ends the step (aux is busy without a gap
     # from the end of chunk 0 to the end of the step): the token-table half of EVERY chunk goes to side, which is idle
@@ -537,6 +568,36 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
 
 
 NO_GUARDS = (C.c_void_p(0), C.c_void_p(0))
+
+
+def _encoder_backward_gated_fused(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2, run, prologue, after_first,
+                                  g: Gates) -> None:
+    """The gated backward when the sweep forms the weight gradients itself: ONE sweep launch, no chunks.  main: loss +
+    dcomb + sweep (raises signal #2 when it starts) + token-table fold + top-up of P.  aux: behind signal #2 (the heads'
+    dcomb chain is done) the heads' parameter gradients -- small GEMMs beside the first ticks --, then R.  side: its decoder
+    segment (enqueued by `after_first`, ticket advanced there), then R.  The caller's next main segment begins with
+    Gates.join (R == 2 per step), exactly as in the chunked form."""
+    (s0, s1, t_lo, t_hi, first, last), = plan.chunks
+
+    def main_seg():
+        if prologue:
+            prologue()
+        plan.heads(1)
+        plan.sweep(s0, s1, g.word(g.P), 0)
+        plan.wgrad(t_lo, t_hi, first, last, 2)        # token table -> embedding.weight, lstm_layer_0.{Wx, bias}
+        g.signal(g.P, g.STRIDE - 2)
+
+    def aux_seg():
+        g.wait(g.P, g.NA, g.STRIDE, 2, advance=True)
+        plan.heads(2)
+        g.signal(g.Q, 1)
+        g.signal(g.R, 1)
+
+    run("main", main_seg, torch.cuda.current_stream())
+    if after_first:
+        after_first()
+    run("aux2_0", lambda: g.signal(g.R, 1), aux2)     # behind the decoder segment in side's stream order
+    run("aux0", aux_seg, aux)
 
 
 def adam_update(store: ParamStore, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,

@@ -282,92 +282,141 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigne
     lo = split_pk(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
 }
 
-template <int NJ>   // wave tile: 128 rows (4 interleaved 32-row tiles) x 32*NJ columns
-__device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, const int by, const int bz) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int m0 = by * 128, n0 = bx * 32 * NJ;
+// Block = 4 waves on ONE 128 x 32*NJ output tile: the waves take the K = 16 steps of the block's K chunk round-robin
+// (the outputs are small and K is long, so parallelism has to come from K; split-K over blocks alone would multiply
+// the float-atomic epilogue -- 128 wave-instructions per tile and slice), their accumulators are summed through LDS
+// (two 32 KB regions: waves 1, 3 -> 0, 2, then 2 -> 0) and every wave commits a quarter of the tile with atomics.
+// MI = 4: 128-row tiles, float4 loads (M % 4 == 0).  MI = 2: 64-row tiles, 8-byte loads -- the accumulators, raw operands
+// and bf16 pieces of a 64 x 64 tile fit ~200 registers, which is what a wave may use BESIDE a persistent LSTM sweep wave
+// (296 of a SIMD's 512): the 128-row form (322 registers) can only run where no sweep block is resident, i.e. it waits
+// for the sweep's chunk to end (measured: step 1.147 vs 1.083 ms).
+template <int MI, int NJ>
+__device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, const int by, const int bz, float* red) {
+    constexpr int TT = MI * NJ;                    // 32 x 32 MFMA tiles of the block tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = by * 32 * MI, n0 = bx * 32 * NJ;
     const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-    const int am = m0 + 4 * r;                     // my 4 rows (columns of the stored A): am .. am + 3
-    const bool aok = am < p.M;                     // M % 4 == 0: all four or none
-    f32x16 acc[4][NJ];
+    const int am = m0 + MI * r;                    // my MI rows (columns of the stored A): am .. am + MI - 1
+    const bool aok = am < p.M;                     // M % MI == 0: all or none
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    float4 ra[8];
-    float rb[8][NJ];
-    auto load = [&](int k0) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const int k = k0 + 8 * h + kk;
-            const bool kok = k < kend;
-            ra[kk] = (kok && aok) ? *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + am) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + 32 * j + r;
-                rb[kk][j] = (kok && n < p.N) ? p.B[(long)k * p.ldb + n] : 0.f;
-            }
-        }
-    };
-    if (kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        // fragments of this K = 16 step: element e of lane (r, h) is k = k0 + 8h + e
-        u32x4_g ah[4], amid[4], al[4], bh[NJ], bm[NJ], bl[NJ];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            unsigned x, y, z;
-            split3(ra[2 * d].x, ra[2 * d + 1].x, x, y, z); ah[0][d] = x; amid[0][d] = y; al[0][d] = z;
-            split3(ra[2 * d].y, ra[2 * d + 1].y, x, y, z); ah[1][d] = x; amid[1][d] = y; al[1][d] = z;
-            split3(ra[2 * d].z, ra[2 * d + 1].z, x, y, z); ah[2][d] = x; amid[2][d] = y; al[2][d] = z;
-            split3(ra[2 * d].w, ra[2 * d + 1].w, x, y, z); ah[3][d] = x; amid[3][d] = y; al[3][d] = z;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                split3(rb[2 * d][j], rb[2 * d + 1][j], x, y, z); bh[j][d] = x; bm[j][d] = y; bl[j][d] = z;
-            }
-        }
-        if (k0 + 16 < kend) load(k0 + 16);          // next step's operands fly under this step's MFMAs
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const bf16x8_t AH = __builtin_bit_cast(bf16x8_t, ah[i]), AM = __builtin_bit_cast(bf16x8_t, amid[i]),
-                               AL = __builtin_bit_cast(bf16x8_t, al[i]);
-                const bf16x8_t BH = __builtin_bit_cast(bf16x8_t, bh[j]), BM_ = __builtin_bit_cast(bf16x8_t, bm[j]),
-                               BL = __builtin_bit_cast(bf16x8_t, bl[j]);
-                f32x16 c = acc[i][j];                 // small terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BM_, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BH, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BM_, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, c, 0, 0, 0);
-                acc[i][j] = c;
-            }
+    float ra[2][8][MI];
+    float rb[2][8][NJ];
+#define SPLIT_LOAD(BUF, K0)                                                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                                            \
+        const int k = (K0) + 8 * h + kk;                                                                          \
+        const bool kok = k < kend;                                                                                \
+        if constexpr (MI == 4) {                                                                                  \
+            const float4 v = (kok && aok) ? *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + am)          \
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);                                      \
+            ra[BUF][kk][0] = v.x; ra[BUF][kk][1] = v.y; ra[BUF][kk][MI > 2 ? 2 : 0] = v.z; ra[BUF][kk][MI > 2 ? 3 : 0] = v.w; \
+        } else {                                                                                                  \
+            const float2 v = (kok && aok) ? *reinterpret_cast<const float2*>(p.A + (long)k * p.lda + am)          \
+                                          : make_float2(0.f, 0.f);                                                \
+            ra[BUF][kk][0] = v.x; ra[BUF][kk][1] = v.y;                                                           \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
+            const int n = n0 + 32 * j + r;                                                                        \
+            rb[BUF][kk][j] = (kok && n < p.N) ? p.B[(long)k * p.ldb + n] : 0.f;                                   \
+        }                                                                                                         \
     }
-    if (kbeg >= kend) return;
+    // one K = 16 step from buffer BUF: split into bf16 pieces, refill the buffer two steps ahead, 6 products per tile
+#define SPLIT_STEP(BUF, K0)                                                                                       \
+    {                                                                                                             \
+        u32x4_g ah[MI], amid[MI], al[MI], bh[NJ], bm[NJ], bl[NJ];                                                 \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                           \
+            unsigned x, y, z;                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                      \
+                split3(ra[BUF][2 * d][i], ra[BUF][2 * d + 1][i], x, y, z); ah[i][d] = x; amid[i][d] = y; al[i][d] = z; \
+            }                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                      \
+                split3(rb[BUF][2 * d][j], rb[BUF][2 * d + 1][j], x, y, z); bh[j][d] = x; bm[j][d] = y; bl[j][d] = z; \
+            }                                                                                                     \
+        }                                                                                                         \
+        if ((K0) + 128 < kend) { SPLIT_LOAD(BUF, (K0) + 128) }                                                    \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
+            const bf16x8_t AH = __builtin_bit_cast(bf16x8_t, ah[i]), AM = __builtin_bit_cast(bf16x8_t, amid[i]),   \
+                           AL = __builtin_bit_cast(bf16x8_t, al[i]);                                              \
+            const bf16x8_t BH = __builtin_bit_cast(bf16x8_t, bh[j]), BM_ = __builtin_bit_cast(bf16x8_t, bm[j]),    \
+                           BL = __builtin_bit_cast(bf16x8_t, bl[j]);                                              \
+            f32x16 c = acc[i][j];                 /* small terms first */                                         \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, c, 0, 0, 0);                                      \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, c, 0, 0, 0);                                      \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BM_, c, 0, 0, 0);                                     \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BH, c, 0, 0, 0);                                      \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BM_, c, 0, 0, 0);                                     \
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, c, 0, 0, 0);                                      \
+            acc[i][j] = c;                                                                                        \
+        }                                                                                                         \
+    }
+    int k0 = kbeg + 16 * wave;                     // my steps: k0, k0 + 64, k0 + 128, ...
+    if (k0 < kend) { SPLIT_LOAD(0, k0) }
+    if (k0 + 64 < kend) { SPLIT_LOAD(1, k0 + 64) }
+    for (; k0 < kend; k0 += 128) {
+        SPLIT_STEP(0, k0)
+        if (k0 + 64 < kend) SPLIT_STEP(1, k0 + 64)
+    }
+#undef SPLIT_STEP
+#undef SPLIT_LOAD
+    // ---- sum the four waves' accumulators: red [2 regions][TT tiles][16][64 lanes]
+    const int reg = wave >> 1;
+    if (wave & 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + 32 * j + r;
-            if (n >= p.N) continue;
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int m = m0 + 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + i;   // MFMA row -> interleaved row
-                if (m < p.M) atomicAdd(p.C + (long)m * p.ldc + n, acc[i][j][q]);
-            }
+                for (int q = 0; q < 16; ++q) red[((reg * TT + i * NJ + j) * 16 + q) * 64 + lane] = acc[i][j][q];
+    }
+    __syncthreads();
+    if (!(wave & 1)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] += red[((reg * TT + i * NJ + j) * 16 + q) * 64 + lane];
+    }
+    __syncthreads();
+    if (!(wave & 1)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[((reg * TT + i * NJ + j) * 16 + q) * 64 + lane] = acc[i][j][q];
+    }
+    __syncthreads();
+    // ---- every wave commits TT / 4 tiles: t = wave * TT/4 + u
+    static_assert(TT % 4 == 0, "a quarter of the tiles per wave");
+#pragma unroll
+    for (int u = 0; u < TT / 4; ++u) {
+        const int t = wave * (TT / 4) + u, i = t / NJ, j = t - i * NJ;
+        const int n = n0 + 32 * j + r;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + MI * ((q & 3) + 8 * (q >> 2) + 4 * h) + i;   // MFMA row -> interleaved row
+            const float v = red[((0 * TT + t) * 16 + q) * 64 + lane] + red[((1 * TT + t) * 16 + q) * 64 + lane];
+            if (m < p.M) atomicAdd(p.C + (long)m * p.ldc + n, v);
         }
+    }
 }
 
-template <int NJ>
-__global__ __launch_bounds__(64) void gemm_split_tn_group_kernel(SplitTNGroup g) {
+template <int MI, int NJ>
+__global__ __launch_bounds__(256) void gemm_split_tn_group_kernel(SplitTNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float split_red[];
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.z >= g.zoff[i + 1]) ++i;
     const SplitTN& p = g.p[i];
-    if ((int)blockIdx.y * 128 >= p.M || (int)blockIdx.x * 32 * NJ >= p.N) return;
-    split_tn_body<NJ>(p, blockIdx.x, blockIdx.y, blockIdx.z - g.zoff[i]);
+    if ((int)blockIdx.y * 32 * MI >= p.M || (int)blockIdx.x * 32 * NJ >= p.N) return;
+    split_tn_body<MI, NJ>(p, blockIdx.x, blockIdx.y, blockIdx.z - g.zoff[i], split_red);
 }
 
 // ARCVAE_GEMM_SPLIT (default 1): the TN "+=" GEMMs (weight gradients, one-hot token-table gradient) on the split-bf16
@@ -384,25 +433,33 @@ int launch_split_tn_group(int n, const SplitTN* probs, hipStream_t stream) {
     SplitTNGroup g;
     g.n = n;
     int Mmax = 0, Nmax = 0, ztot = 0;
-    static const int target = arcvae_env_int("ARCVAE_SPLIT_WAVES", 1024);   // waves in flight wanted (4 per CU)
+    static const int target = arcvae_env_int("ARCVAE_SPLIT_BLOCKS", 256);   // blocks (of 4 waves) wanted per launch
     for (int i = 0; i < n; ++i) {
         g.p[i] = probs[i];
         Mmax = max(Mmax, probs[i].M); Nmax = max(Nmax, probs[i].N);
     }
-    const int tiles = ceil_div(Mmax, 128) * ceil_div(Nmax, 64);
+    // ARCVAE_SPLIT_TILE: 2 (default) = 64 x 64 tiles (fits beside a persistent sweep), 4 = 128 x 64
+    static const int mi = arcvae_env_int("ARCVAE_SPLIT_TILE", 2) == 4 ? 4 : 2;
+    const int tiles = ceil_div(Mmax, 32 * mi) * ceil_div(Nmax, 64);
     for (int i = 0; i < n; ++i) {
         SplitTN& p = g.p[i];
-        int z = min(ceil_div(target, tiles * n), max(1, p.K / 128));           // at least 128 of K per slice
+        int z = min(ceil_div(target, tiles * n), max(1, p.K / 256));           // at least 256 of K per block (4 steps a wave)
         z = max(1, z);
-        p.kchunk = ceil_div(ceil_div(p.K, z), 16) * 16;
+        p.kchunk = ceil_div(ceil_div(p.K, z), 64) * 64;
         z = ceil_div(p.K, p.kchunk);
         g.zoff[i] = ztot;
         ztot += z;
     }
     g.zoff[n] = ztot;
     for (int i = n; i < ARCVAE_SPLIT_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.zoff[i + 1] = ztot; }
-    dim3 grid(ceil_div(Nmax, 64), ceil_div(Mmax, 128), ztot);
-    hipLaunchKernelGGL(gemm_split_tn_group_kernel<2>, grid, dim3(64), 0, stream, g);
+    dim3 grid(ceil_div(Nmax, 64), ceil_div(Mmax, 32 * mi), ztot);
+    const size_t lds = sizeof(float) * 2 * (mi * 2) * 16 * 64;                   // two accumulator images: 32 / 64 KB
+    if (mi == 4) {
+        (void)hipFuncSetAttribute((const void*)gemm_split_tn_group_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_split_tn_group_kernel<4, 2>), grid, dim3(256), lds, stream, g);
+    } else {
+        hipLaunchKernelGGL((gemm_split_tn_group_kernel<2, 2>), grid, dim3(256), lds, stream, g);
+    }
     return arcvae_launch_status();
 }
 

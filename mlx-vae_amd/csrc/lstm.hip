@@ -1333,6 +1333,14 @@ struct PersistRsArgs {
     PersistBwdArgs b;
     const float* W[3];        // row-major [4H,H]: cell(l=1) Wh_1, cell(l=0) Wh_0, xproj(0) Wx_1   (slot order; L = 1: W[0] = Wh_0)
     float* part;              // [2 parity][S][8 XCDs][32 consumers][32 producers][64]  partial sums in flight
+    // fused weight gradients (FW variant): accumulated on chip over the launch's ticks, added ("+=") at its end
+    const float* hseq;        // [L,T,B,H] hidden states of the forward sweep
+    const int32_t* x_tb;      // [T,B] tokens (layer-0 token-table gradient)
+    float* dW[3];             // gradient buffers [4H,H] of: Wh_top; then (L = 2) Wx_1, Wh_0
+    float* dbias1;            // [4H] gradient of bias_1 (L = 2), else null
+    float* dtable;            // [V,4H] token-table gradient workspace
+    int V;
+    int fw_dbg;               // timing experiments only (ARCVAE_FW_DEBUG): 1 no h loads, 2 no products, 4 no token table
 };
 
 // MF = 1 (registers only): the contraction on v_mfma_f32_4x4x1 (16 blocks of 4x4, K = 1) instead of 16x16x4.  An XCD owns
@@ -1341,15 +1349,29 @@ struct PersistRsArgs {
 // instruction (8 cycles) covers 8 rows x 32 units for one k without a padded row: 192 instructions, 0.64 us.  Weights
 // are the A operand (lane (rg, ug, i): W[k][32ch + 4ug + i], 192 VGPRs), the local gate gradients the B operand
 // (lane (rg, ug, j): dG[4rg + j][k], broadcast reads from LDS); a lane ends up with 4 consecutive units of one row.
-template <int LL, bool WR, int MF>   // WR: the weight slices live in registers, else in LDS
+//
+// FW = true: the WEIGHT GRADIENTS ride in the same kernel.  The separate weight-gradient GEMMs were what the step lost most
+// on: run beside the sweep they doubled its tick (2.47 -> 4.3-5.2 us over the second chunk: streaming loads in the memory
+// queue of every CU that is an endpoint of the exchange), run after it they are the step's tail -- 120 us of a 1.06 ms
+// step either way (profiles/r02_wgrad_experiments.txt).  But a CU already HOLDS one operand: the gate gradients of its 32
+// gate columns and its XCD's 8 rows, one tick old, in LDS.  dWh_l[my 32 rows, :] += dG_l[t]^T . h_l[t-1] needs only those 8
+// rows of h (8 KB per source and tick, prefetched a tick ahead, plain cached loads: nobody waits for them) -- an outer
+// product with K = 8 per tick on v_mfma_f32_32x32x2: 24 instructions per wave and tick, issued where the chain leaves the
+// matrix pipe idle (behind the flag store while the flags travel, and under the gather's loads), accumulated in 96
+// registers per lane over the whole sweep and added to the gradient buffers once, at the end (8 XCDs x 3 sources:
+// float atomics, full 128-B rows).  The token-table gradient (layer 0's input side) is an LDS scatter-add by token, the
+// bias gradient a per-thread running sum.  No aux-stream GEMMs, no chunks, nothing beside the sweep.
+template <int LL, bool WR, int MF, bool FW = false>   // WR: the weight slices live in registers, else in LDS
 __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
     static_assert(MF == 0 || WR, "the 4x4x1 form keeps its weights in registers");
+    static_assert(!FW || MF == 1, "fused weight gradients: 4x4x1 form only");
     const PersistBwdArgs& a = ar.b;
     constexpr int UW = 8, S = 2 * LL - 1, WS = 36;   // WS: padded row stride of the weight image (bank-conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wloc = lds;                                // [S][256 units][WS]: W[my gate col k][unit], k-contiguous (LDS variant)
     float* dgl = wloc + (WR ? 0 : S * 256 * WS);      // [LL][16 rows][32 gate cols of mine]  (rows >= 8 stay zero)
     float* dxl = dgl + LL * 16 * 32;                  // [2][64]
+    float* dtl = dxl + 128;                           // FW: [V][33] token-table gradient of my 32 gate columns
     __shared__ unsigned s_role, s_xcc, s_ok;
     arcvae_set_prio(a.prio);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1408,9 +1430,66 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         }
     }
     for (int i = tid; i < LL * 16 * 32; i += 256) dgl[i] = 0.f;
+    if constexpr (FW)
+        for (int i = tid; i < ar.V * 33; i += 256) dtl[i] = 0.f;   // row stride 33: rows of different tokens on different banks
     __syncthreads();
     const int row0 = xcc * RX;
     const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
+    // ---- fused weight gradients: sources q = 0: dWh_top (A = dG_top[t], B = h_top[t-1]); L = 2: q = 1: dWx_1 (dG_1[t],
+    // h_0[t]), q = 2: dWh_0 (dG_0[t], h_0[t-1]).  32x32x2: A lane (c = lane & 31, k = lane >> 5) = dG[row 2kk + k][c],
+    // B lane = h[row 2kk + k][64 wave + 32 tile + (lane & 31)]; D register g, lane: gate column (g&3) + 8(g>>2) + 4(lane>>5).
+    constexpr int NQ = FW ? S : 1;
+    f32x16 wacc[NQ][2];
+    float wa[NQ][4], wb[NQ][4][2];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    bool wq_on[NQ];
+    if constexpr (FW) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            wq_on[q] = false;
+#pragma unroll
+            for (int tl_ = 0; tl_ < 2; ++tl_)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) wacc[q][tl_][g] = 0.f;
+        }
+    }
+    // operands of the gate gradients that tick sp left in dgl: A from LDS now (the next epilogue overwrites it), B requested
+    auto wg_prepare = [&](int sp, int q_lo, int q_hi) {
+        if constexpr (FW) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q < q_lo || q >= q_hi) continue;
+                const int lq = (q == 2) ? 0 : LL - 1;                          // layer of the gate gradients
+                const int tq = T - 1 - (sp - 2 * (LL - 1 - lq));               // their time step
+                const int lh = (q == 1) ? 0 : lq;                              // layer / time of the hidden states
+                const int th = (q == 1) ? tq : tq - 1;
+                wq_on[q] = tq >= 0 && tq < T && th >= 0;                       // block-uniform
+                if (!wq_on[q]) continue;
+                const float* hp = ar.hseq + lh * lH + (long)th * sH + 64 * wave + (lane & 31);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int row = 2 * kk + (lane >> 5);
+                    wa[q][kk] = dgl[(lq * 16 + row) * 32 + (lane & 31)];
+                    const bool rok = row < RX && row0 + row < B && !(ar.fw_dbg & 1);
+                    const float* hr = hp + (long)min(row0 + row, B - 1) * H;
+                    wb[q][kk][0] = rok ? hr[0] : 0.f;
+                    wb[q][kk][1] = rok ? hr[32] : 0.f;
+                }
+            }
+        }
+    };
+    auto wg_mfma = [&](int q) {
+        if constexpr (FW) {
+            if (q < NQ && wq_on[q < NQ ? q : 0] && !(ar.fw_dbg & 2)) {
+                const int qq = q < NQ ? q : 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    wacc[qq][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[qq][kk], wb[qq][kk][0], wacc[qq][0], 0, 0, 0);
+                    wacc[qq][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[qq][kk], wb[qq][kk][1], wacc[qq][1], 0, 0, 0);
+                }
+            }
+        }
+    };
     const int slot = tid >> 6, p = tid & 63;          // slots: cell(l) -> LL-1-l, xproj(0) -> LL (as lstm_bwd_persist_kernel)
     const bool is_cell = slot < LL;
     const int el = is_cell ? (LL - 1 - slot) : (slot - LL);
@@ -1440,6 +1519,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                 if (el < LL - 1) ext_v = a.dxs[((long)el * RS + (t % RS)) * sH + hb];
             }
         }
+        int tok = 0;
+        if constexpr (FW) {
+            if (eact && is_cell && jact && el == 0) tok = min(max(ar.x_tb[(long)t * B + eb], 0), ar.V - 1);
+        }
         // first tick of a chunk: my gate columns of the gradients the previous chunk left in memory
         if (s == a.s_begin) {
             for (int i = tid; i < LL * 8 * 32; i += 256) {
@@ -1452,6 +1535,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             }
             __syncthreads();
         }
+        if (s > a.s_begin) wg_prepare(s - 1, 0, 2);   // FW (sources 0, 1; source 2 behind the flag store): operands of the weight-gradient products of the previous tick's gate gradients
         if (tr) a.trace[2 * s] = wall_clock64();
         // ---- partial products of the S slots from my local gate gradients; wave w covers units [64w, 64w + 64)
         float* pbase = ar.part + (long)(s & 1) * S * part_src + (long)xcc * 32 * 32 * 64;
@@ -1528,6 +1612,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         ps_stores_in_l2();                                       // my partials have reached the XCD's L2
         __syncthreads();
         if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // FW: the flags are travelling and the matrix pipe is idle: first part of the weight-gradient products
+        if constexpr (LL > 1) { if (s > a.s_begin) wg_prepare(s - 1, 2, 3); }   // its loads fly while the flags are polled
+        wg_mfma(0);
+        if constexpr (LL > 1) wg_mfma(1);
         // ---- every CU of my XCD has published its partials of tick s
         if (wave == 0) {
             unsigned spins = 0;
@@ -1546,17 +1634,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         if (!s_ok) return;
         // ---- gather: the 32 pieces of my (slot, row, unit)
         float dh = 0.f;
-        if (eact && jact) {
+        {
             // my role's 32 pieces of this slot: 8 KB contiguous, [producer][64 (row, unit) values]
             // (slot = tid >> 6 is wave-uniform: say so, or the compiler wraps every load in a waterfall loop over the
             // descriptor's lanes with a vmcnt(0) inside -- 32 serialised round trips)
             const int slot_u = __builtin_amdgcn_readfirstlane(slot);
-            const __amdgpu_buffer_rsrc_t rs = ps_rsrc(pbase + slot_u * part_src + ((long)role * 32) * 64, 32 * 64 * 4);
+            const __amdgpu_buffer_rsrc_t rs = ps_rsrc(pbase + (slot_u < S ? slot_u : 0) * part_src + ((long)role * 32) * 64, 32 * 64 * 4);
             float v[32];
+            const bool gact = eact && jact;
+            if (gact) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = ps_load_sc1(rs, (unsigned)((i * 64 + p) * 4));
+                for (int i = 0; i < 32; ++i) v[i] = ps_load_sc1(rs, (unsigned)((i * 64 + p) * 4));
+            }
+            if constexpr (LL > 1) wg_mfma(2);   // FW: the rest of the weight-gradient products, under the gather's loads
+            if (gact) {
 #pragma unroll
-            for (int i = 0; i < 32; i += 4) dh += (v[i] + v[i + 1]) + (v[i + 2] + v[i + 3]);
+                for (int i = 0; i < 32; i += 4) dh += (v[i] + v[i + 1]) + (v[i + 2] + v[i + 3]);
+            }
         }
         if (eact && jact) {
             if (!is_cell) {
@@ -1577,10 +1671,46 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                 dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
                 float* dl = dgl + (el * 16 + erow) * 32 + ul;        // my gate columns stay on the CU for the next tick
                 dl[0] = d_i; dl[8] = d_f; dl[16] = d_g; dl[24] = d_o;
+                if constexpr (FW) {
+                    if (el > 0) {                                    // bias gradient of the layers above 0: running sum
+                        bsum[0] += d_i; bsum[1] += d_f; bsum[2] += d_g; bsum[3] += d_o;
+                    } else if (!(ar.fw_dbg & 4)) {                   // layer 0: token-table gradient (LDS scatter-add)
+                        float* tp = dtl + tok * 33 + ul;
+                        atomicAdd(tp, d_i); atomicAdd(tp + 8, d_f); atomicAdd(tp + 16, d_g); atomicAdd(tp + 24, d_o);
+                    }
+                }
             }
         }
         __syncthreads();
         if (tr) a.trace[2 * s + 1] = wall_clock64();
+    }
+    if constexpr (FW) {
+        // ---- the last tick's gate gradients, then everything this launch accumulated goes to the gradient buffers
+        wg_prepare(a.s_end - 1, 0, NQ);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wg_mfma(q);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int tl_ = 0; tl_ < 2; ++tl_)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int c = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);              // my gate column (MFMA row)
+                    atomicAdd(ar.dW[q] + (long)((c >> 3) * H + role * UW + (c & 7)) * H + 64 * wave + 32 * tl_ + (lane & 31),
+                              wacc[q][tl_][g]);
+                }
+        if (LL > 1 && ar.dbias1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = bsum[g];
+                v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);   // over my XCD's rows
+                if (is_cell && el > 0 && erow == 0) atomicAdd(ar.dbias1 + g * H + unit, v);
+            }
+        }
+        for (int i = tid; i < ar.V * 32; i += 256) {
+            const float v = dtl[(i >> 5) * 33 + (i & 31)];
+            if (v != 0.f) atomicAdd(ar.dtable + (long)(i >> 5) * G + ((i & 31) >> 3) * H + role * UW + (i & 7), v);
+        }
     }
 }
 
@@ -1819,12 +1949,15 @@ extern "C" int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L) {
 // Reduce-scatter form of the persistent BPTT sweep (lstm_bwd_persist_rs_kernel): H = 256, L <= 2, B <= 64.
 //   Wx / Wh: HOST arrays of the row-major weights (as arcvae_enc_lstm_backward);  part_ws: 2 * (2L-1) * 8 * 32 * 32 * 64
 //   floats of scratch for the partial sums in flight.  Everything else as arcvae_enc_lstm_backward_persistent.
-extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
-                                                      const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
-                                                      float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
-                                                      unsigned* start_signal, int B, int T, int H, int L, int s_begin,
-                                                      int s_end, int chunk_index, unsigned long long* trace,
-                                                      hipStream_t stream) {
+// fused != null: the FW variant (weight gradients accumulated in the kernel, see lstm_bwd_persist_rs_kernel).
+namespace {
+struct FusedWgrad {
+    const float* hseq; const int32_t* x_tb; float* const* dWx; float* const* dWh; float* const* dbias; float* dtable; int V;
+};
+int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* cseq, const float* gseq,
+                  const float* dh_top, int ld_dh_top, float* dG, float* dcs, float* dxs, float* part_ws,
+                  unsigned* sync_ws, unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
+                  int chunk_index, unsigned long long* trace, const FusedWgrad* fused, hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !part_ws || !sync_ws) return ARCVAE_ERR_ARG;
     if (H != 256 || L < 1 || L > 2 || B < 1 || B > 64 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
@@ -1846,26 +1979,74 @@ extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, co
     else { ar.W[0] = Wh[0]; ar.W[1] = Wh[0]; ar.W[2] = Wh[0]; }
     for (int i = 0; i < 2 * L - 1; ++i) if (!ar.W[i]) return ARCVAE_ERR_ARG;
     ar.part = part_ws;
+    ar.fw_dbg = arcvae_env_int("ARCVAE_FW_DEBUG", 0);
+    ar.hseq = nullptr; ar.x_tb = nullptr; ar.dW[0] = ar.dW[1] = ar.dW[2] = nullptr; ar.dbias1 = nullptr; ar.dtable = nullptr; ar.V = 0;
+    if (fused) {
+        if (!fused->hseq || !fused->x_tb || !fused->dWx || !fused->dWh || !fused->dbias || !fused->dtable || fused->V < 1 ||
+            fused->V > 128)
+            return ARCVAE_ERR_ARG;
+        ar.hseq = fused->hseq; ar.x_tb = fused->x_tb; ar.dtable = fused->dtable; ar.V = fused->V;
+        ar.dW[0] = fused->dWh[L - 1];                                   // q = 0: Wh of the top layer
+        if (L == 2) { ar.dW[1] = fused->dWx[1]; ar.dW[2] = fused->dWh[0]; ar.dbias1 = fused->dbias[1]; }
+        else { ar.dW[1] = ar.dW[0]; ar.dW[2] = ar.dW[0]; }
+        for (int i = 0; i < 2 * L - 1; ++i) if (!ar.dW[i]) return ARCVAE_ERR_ARG;
+        if (L == 2 && !ar.dbias1) return ARCVAE_ERR_ARG;
+        if (chunk_index == 0) {                                          // the token table accumulates over the sweep's chunks
+            const int rc = arcvae_zero(fused->dtable, fused->V, 4 * H, 4 * H, stream);
+            if (rc != ARCVAE_OK) return rc;
+        }
+    }
     // ARCVAE_RS_WREG=0: weight slices in LDS instead of registers.  Either way at least 81 KB of LDS: one block per CU.
-    const bool wreg = arcvae_env_int("ARCVAE_RS_WREG", 1) != 0;
-    size_t lds = sizeof(float) * ((wreg ? 0 : (size_t)(2 * L - 1) * 256 * 36) + (size_t)L * 16 * 32 + 128);
+    const bool wreg = arcvae_env_int("ARCVAE_RS_WREG", 1) != 0 || fused;
+    size_t lds = sizeof(float) * ((wreg ? 0 : (size_t)(2 * L - 1) * 256 * 36) + (size_t)L * 16 * 32 + 128 + (fused ? 128 * 33 : 0));
     if (lds < persist_lds_floor()) lds = persist_lds_floor();
     auto launch = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, stream, ar);
     };
     // ARCVAE_RS_MFMA: 1 (default) = 4x4x1 blocks, 0 = 16x16x4 tiles (registers only; the LDS variant always uses 16x16x4)
-    const bool mf = wreg && arcvae_env_int("ARCVAE_RS_MFMA", 1) != 0;
+    const bool mf = (wreg && arcvae_env_int("ARCVAE_RS_MFMA", 1) != 0) || fused;
     if (L == 1) {
-        if (mf) launch(lstm_bwd_persist_rs_kernel<1, true, 1>);
+        if (fused) launch(lstm_bwd_persist_rs_kernel<1, true, 1, true>);
+        else if (mf) launch(lstm_bwd_persist_rs_kernel<1, true, 1>);
         else if (wreg) launch(lstm_bwd_persist_rs_kernel<1, true, 0>);
         else launch(lstm_bwd_persist_rs_kernel<1, false, 0>);
     } else {
-        if (mf) launch(lstm_bwd_persist_rs_kernel<2, true, 1>);
+        if (fused) launch(lstm_bwd_persist_rs_kernel<2, true, 1, true>);
+        else if (mf) launch(lstm_bwd_persist_rs_kernel<2, true, 1>);
         else if (wreg) launch(lstm_bwd_persist_rs_kernel<2, true, 0>);
         else launch(lstm_bwd_persist_rs_kernel<2, false, 0>);
     }
     return arcvae_launch_status();
+}
+}  // namespace
+
+extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
+                                                      const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
+                                                      float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
+                                                      unsigned* start_signal, int B, int T, int H, int L, int s_begin,
+                                                      int s_end, int chunk_index, unsigned long long* trace,
+                                                      hipStream_t stream) {
+    return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, sync_ws, start_signal, B, T, H, L,
+                         s_begin, s_end, chunk_index, trace, nullptr, stream);
+}
+
+// The same sweep with the weight gradients of the stack formed INSIDE it (FW variant of lstm_bwd_persist_rs_kernel):
+// replaces arcvae_enc_lstm_backward_persistent_rs + the per-layer GEMMs, bias sums and token segment-sum of
+// arcvae_enc_lstm_wgrad for the same tick range.  "+=" into dWh[l] (all l), dWx[l] and dbias[l] (l >= 1); the layer-0 input
+// side arrives as dtable_ws [V,4H] (zeroed by the chunk_index == 0 call), to be folded by arcvae_table_finalize.
+//   hseq [L,T,B,H], x_tb [T,B]: the forward sweep's outputs / inputs;  dWx, dWh, dbias: HOST arrays of device pointers.
+extern "C" int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* Wh, const float* cseq,
+                                              const float* gseq, const float* hseq, const int32_t* x_tb,
+                                              const float* dh_top, int ld_dh_top, float* dG, float* dcs, float* dxs,
+                                              float* part_ws, unsigned* sync_ws, unsigned* start_signal,
+                                              float* const* dWx, float* const* dWh, float* const* dbias,
+                                              float* dtable_ws, int B, int T, int V, int H, int L, int s_begin, int s_end,
+                                              int chunk_index, unsigned long long* trace, hipStream_t stream) {
+    FusedWgrad f;
+    f.hseq = hseq; f.x_tb = x_tb; f.dWx = dWx; f.dWh = dWh; f.dbias = dbias; f.dtable = dtable_ws; f.V = V;
+    return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, sync_ws, start_signal, B, T, H, L,
+                         s_begin, s_end, chunk_index, trace, &f, stream);
 }
 
 // BPTT for the stack.  Only h_{T-1} of the top layer receives an external gradient

@@ -372,3 +372,30 @@ def test_persistent_sweeps_and_their_fallback(env, H, L, B, T, C, monkeypatch):
         else:
             assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("L,B,T", [(2, 64, 12), (1, 37, 9), (2, 21, 5)])
+def test_fused_weight_gradient_sweep(L, B, T, monkeypatch):
+    """ARCVAE_FUSED_WGRAD=1: the reduce-scatter BPTT sweep that forms dWh_l, dWx_l, dbias_l and the token-table gradient
+    inside the kernel (FW variant of lstm_bwd_persist_rs_kernel; opt-in: slower than the GEMM form) -- every parameter
+    gradient against the oracle, norm-wise and element-wise, ragged batches and a single layer included."""
+    monkeypatch.setenv("ARCVAE_FUSED_WGRAD", "1")
+    cfg = O.Config(vocab_size=60, embedding_dim=24, hidden_dim=256, latent_dim=16, num_conditions=1, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    from arcvae_hip import engine as E
+    ws = eng.workspace(B, T)
+    assert E.EncoderBackwardPlan(enc, ws, eng.d).fused
+    for _ in range(2):                                  # second step = replayed segments
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+        torch.cuda.synchronize()
+        eng.check_gates()
+        for name, g in grads.items():
+            mod, pname = name.split(".", 1)
+            got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+            if np.abs(g).max() == 0.0:
+                assert np.abs(got).max() == 0.0, name
+            else:
+                assert rel_err(got, g) < TOL, name
+                assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)

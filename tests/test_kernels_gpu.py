@@ -67,6 +67,40 @@ def test_gemm_strided_c():
     assert rel_err(dC.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K,ldc_pad", [(1024, 256, 3072, 0), (80, 1024, 2000, 0), (256, 64, 100, 3), (36, 72, 531, 0),
+                                           (512, 192, 16, 0), (128, 40, 4097, 5)])
+def test_split_bf16_tn_gemm_has_f32_accuracy(M, N, K, ldc_pad, monkeypatch):
+    """C += A^T . B on the split-bf16 kernel (three bf16 pieces per operand, six products, f32 accumulate:
+    csrc/gemm.hip gemm_split_tn_group_kernel) against fp64, next to the exact-f32 MFMA kernel on the same data: the
+    split path must sit in the same accuracy class (its worst element error within 2x the f32 kernel's, plus a
+    floor), and pass the 1e-4 / 1e-6 element-wise parity criterion by orders of magnitude."""
+    from arcvae_hip import _lib
+    from helpers import elem_err
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.standard_normal((K, M)) * np.exp(rs.uniform(-3, 3, size=(K, 1)))).astype(np.float32)   # wide dynamic range
+    Bm = rs.standard_normal((K, N)).astype(np.float32)
+    ld = N + ldc_pad
+    C0 = rs.standard_normal((M, ld)).astype(np.float32)
+    ref = C0.astype(np.float64).copy()
+    ref[:, :N] += A.T.astype(np.float64) @ Bm.astype(np.float64)
+    mag = np.abs(A.T.astype(np.float64)) @ np.abs(Bm.astype(np.float64))       # sum |a||b| per element
+    dA, dB = _dev(A), _dev(Bm)
+    out = {}
+    for name, flags in (("split", _lib.GEMM_ACCUMULATE | _lib.GEMM_SPLITK), ("f32", _lib.GEMM_ACCUMULATE)):
+        dC = _dev(C0)
+        _lib.gemm(True, False, M, N, K, dA, M, dB, N, dC, ld, None, flags)
+        torch.cuda.synchronize()
+        got = dC.cpu().numpy().astype(np.float64)
+        if ldc_pad:
+            assert np.array_equal(got[:, N:], C0[:, N:].astype(np.float64))   # padding columns untouched
+        out[name] = np.abs(got[:, :N] - ref[:, :N]) / (mag + 1e-30)
+    assert out["split"].max() <= max(2.0 * out["f32"].max(), 2e-7), (out["split"].max(), out["f32"].max())
+    dC = _dev(C0)
+    _lib.gemm(True, False, M, N, K, dA, M, dB, N, dC, ld, None, _lib.GEMM_ACCUMULATE | _lib.GEMM_SPLITK)
+    torch.cuda.synchronize()
+    assert elem_err(dC.cpu().numpy()[:, :N], ref[:, :N], 1e-4, 1e-6)[0] < 0.2
+
+
 def test_adam_matches_mlx_formula():
     from arcvae_hip import _lib
     from arcvae_hip._lib import call, ptr, stream_ptr
