@@ -92,11 +92,19 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
  * its block roles from its own counters.  trace (optional diagnostic): per-tick {start,end} stamps of one block at
  * trace[2s..2s+1] (forward: s < T+L-1; BPTT: the sweep's global tick index s < T+2(L-1)). */
 int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L);
+/* (the sweep reads the row-major Wx / Wh themselves: no k-chunk-major copy.  wT_bwd, optional: also write the BPTT
+ * layouts for a launch-based arcvae_enc_lstm_backward(retile = 0) of the same step.  flags bit 0: sync_ws has been
+ * re-armed by arcvae_enc_prologue.) */
 int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
-                                       float* gseq, float* wt, float* wT_bwd, unsigned* sync_ws, unsigned* start_signal,
-                                       int B, int T, int V, int H, int L, unsigned long long* trace,
+                                       float* gseq, float* wT_bwd, unsigned* sync_ws, unsigned* start_signal,
+                                       int B, int T, int V, int H, int L, int flags, unsigned long long* trace,
                                        arcvae_stream_t stream);
+/* The byte-moving launches in front of the persistent forward sweep as one: x_tb = x_bt^T (arcvae_transpose_tokens),
+ * zero_f32[0..n_zero) = 0 (optional: the encoder's gradient buffer), sync_ws[0..n_sync) = 0 (optional: the sweep's
+ * re-arm). */
+int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, unsigned* sync_ws, int n_sync,
+                        int B, int T, arcvae_stream_t stream);
 int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, const float* dh_top, int ld_dh_top,
                                         float* dG, float* dcs, float* dxs, const float* wT, unsigned* sync_ws,

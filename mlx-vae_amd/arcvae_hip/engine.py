@@ -161,25 +161,36 @@ def persistent_forward_ok(ws: Workspace, d: ModelDims) -> bool:
 
 
 def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: float,
-                    start_signal: Optional[C.c_void_p] = None) -> None:
+                    start_signal: Optional[C.c_void_p] = None, zero_grad: bool = False) -> None:
     """models/encoder.py:76-153 + per-rank latent statistics.  start_signal (persistent sweep only): device word
-    bumped when the sweep starts."""
+    bumped when the sweep starts.  zero_grad: also clear the encoder's gradient buffer (start of a training step)."""
     B, T = ws.B, ws.T
     G = 4 * d.H
     s = stream_ptr()
-    call("arcvae_transpose_tokens", ptr(ws.x), ptr(ws.x_tb), B, T, s)
-    # table0 = embedding . Wx_0^T + bias_0   ([V,4H]; the layer-0 input projection of every token)
-    call("arcvae_gemm_f32", 0, 1, d.V, G, d.E, ptr(enc.p("embedding.weight")), d.E,
-         ptr(enc.p("lstm_layer_0.Wx")), d.E, ptr(ws.table0), G, ptr(enc.p("lstm_layer_0.bias")), 0, s)
     wx, _k1 = _layer_ptrs(enc, d.L, "Wx", skip0=True)
     wh, _k2 = _layer_ptrs(enc, d.L, "Wh")
     bs, _k3 = _layer_ptrs(enc, d.L, "bias", skip0=True)
-    wT = ptr(ws.wT) if hasattr(ws, "wT") else C.c_void_p(0)
     if persistent_forward_ok(ws, d):
+        # Two launches in front of the sweep instead of six: [tokens^T + the gradient buffer's zero fill + the sweep's
+        # re-arm] and table0 = embedding . Wx_0^T + bias_0 ([V,4H]: the layer-0 input projection of every token).  The
+        # sweep reads the row-major weights itself; k-chunk-major BPTT copies are only written for a launch-based backward.
+        grad = enc.grad if zero_grad else None
+        call("arcvae_enc_prologue", ptr(ws.x), ptr(ws.x_tb), ptr(grad), C.c_long(grad.numel() if grad is not None else 0),
+             ptr(ws.psync), 272, B, T, s)
+        call("arcvae_gemm_f32", 0, 1, d.V, G, d.E, ptr(enc.p("embedding.weight")), d.E,
+             ptr(enc.p("lstm_layer_0.Wx")), d.E, ptr(ws.table0), G, ptr(enc.p("lstm_layer_0.bias")), 0, s)
+        need_wT = hasattr(ws, "wT") and not bptt_reduce_scatter_ok(ws, d)
         call("arcvae_enc_lstm_forward_persistent", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq),
-             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, ptr(ws.psync),
-             start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L, ptr(ws.trace_fwd), s)
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wT) if need_wT else C.c_void_p(0), ptr(ws.psync),
+             start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L, 1, ptr(ws.trace_fwd), s)
     else:
+        if zero_grad:
+            enc.grad.zero_()
+        call("arcvae_transpose_tokens", ptr(ws.x), ptr(ws.x_tb), B, T, s)
+        # table0 = embedding . Wx_0^T + bias_0   ([V,4H]; the layer-0 input projection of every token)
+        call("arcvae_gemm_f32", 0, 1, d.V, G, d.E, ptr(enc.p("embedding.weight")), d.E,
+             ptr(enc.p("lstm_layer_0.Wx")), d.E, ptr(ws.table0), G, ptr(enc.p("lstm_layer_0.bias")), 0, s)
+        wT = ptr(ws.wT) if hasattr(ws, "wT") else C.c_void_p(0)
         if start_signal is not None:
             call("arcvae_gate_set", start_signal, 1, 1, s)
         call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
@@ -788,9 +799,7 @@ class StepEngine:
             self.ev_dec_bwd.record(self.side)
 
     def _enc_fwd(self, ws: Workspace, backward: bool, start_signal=None) -> None:
-        if backward:
-            self.enc.grad.zero_()
-        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]), start_signal)
+        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]), start_signal, zero_grad=backward)
 
     def enqueue_encoder_forward(self, ws: Workspace, run=_inline, backward: bool = True, start_signal=None) -> None:
         """Encoder forward on the current stream; leaves this process's partial latent `stats` (the CE slot

@@ -727,7 +727,7 @@ struct PersistArgs {
     const int32_t* x_tb;
     const float* table0;
     const float* bias[ARCVAE_MAX_LAYERS];   // l >= 1
-    const float* wt;                         // k-chunk-major weights [(2L-1)][H/16][4H][16]: Wh_l at l, Wx_l at L+l-1
+    const float* W[7];                       // the row-major weights [4H,H] themselves: Wh_l at l, Wx_l (l >= 1) at L+l-1 (L <= 4)
     float* hseq;
     float* cseq;
     float* gseq;
@@ -825,13 +825,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
         return;
     }
     const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
-    // stationary weights: permuted rows [role*CW, +CW) of every source
+    // stationary weights: permuted rows [role*CW, +CW) of every source, read ONCE per launch straight from the row-major
+    // parameters (no k-chunk-major copy, i.e. no re-layout launch in front of the sweep: round 2).  Permuted row rp of a
+    // source = unit 4(rp >> 4) + (rp & 3), gate (rp >> 2) & 3: the 16 gate columns of 4 units are consecutive.
+    auto wsrc = [&](int si, int kc, int rp, int ko) -> const float* {
+        return a.W[si] + (long)(((rp >> 2) & 3) * H + (rp >> 4) * 4 + (rp & 3)) * H + 16 * kc + ko;
+    };
     const int r = lane & 15, q4 = (lane >> 4) * 4;
     const int rg = lane >> 5, cg = (lane >> 2) & 7, ij = lane & 3;   // 4x4x1 blocks: (row group, column group), index in block
     f32x4 wr[(WREG && !MF) ? S : 1][(WREG && !MF) ? CHW : 1][(WREG && !MF) ? NT : 1];
     f32x4 wq[MF ? S : 1][MF ? CHW : 1][MF ? 4 : 1];   // [source][16-wide k chunk of my quarter][4-group]: W[k..k+3][4cg + ij]
     {
-        const long wsz = (long)H * G;
         if constexpr (MF == 1) {
 #pragma unroll
             for (int si = 0; si < S; ++si)
@@ -839,8 +843,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                 for (int c = 0; c < CHW; ++c)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
-                        wq[si][c][g4] = *reinterpret_cast<const f32x4*>(
-                            a.wt + si * wsz + ((long)(wave * CHW + c) * G + role * CW + 4 * cg + ij) * 16 + 4 * g4);
+                        wq[si][c][g4] = *reinterpret_cast<const f32x4*>(wsrc(si, wave * CHW + c, role * CW + 4 * cg + ij, 4 * g4));
         } else if constexpr (WREG) {
 #pragma unroll
             for (int si = 0; si < S; ++si)
@@ -848,14 +851,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                 for (int c = 0; c < CHW; ++c)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        wr[si][c][n] = *reinterpret_cast<const f32x4*>(
-                            a.wt + si * wsz + ((long)(wave * CHW + c) * G + role * CW + 16 * n + r) * 16 + q4);
+                        wr[si][c][n] = *reinterpret_cast<const f32x4*>(wsrc(si, wave * CHW + c, role * CW + 16 * n + r, q4));
         } else {
             for (int i = tid; i < S * NCH * CW * 4; i += 256) {
                 const int si = i / (NCH * CW * 4), rem = i - si * (NCH * CW * 4);
                 const int kc = rem / (CW * 4), c4 = rem - kc * (CW * 4);
-                reinterpret_cast<float4*>(wl)[i] =
-                    *reinterpret_cast<const float4*>(a.wt + si * wsz + ((long)kc * G + role * CW) * 16 + c4 * 4);
+                reinterpret_cast<float4*>(wl)[i] = *reinterpret_cast<const float4*>(wsrc(si, kc, role * CW + (c4 >> 2), (c4 & 3) * 4));
             }
         }
     }
@@ -1776,6 +1777,7 @@ static int tile_all_weights(const float* const* Wx, const float* const* Wh, floa
     int n = 0;
     for (int pass = 0; pass < (wT_bwd ? 2 : 1); ++pass) {
         float* base = pass == 0 ? wt : wT_bwd;
+        if (!base) continue;                       // wt == null: only the BPTT layouts (persistent forward reads row-major)
         for (int l = 0; l < L; ++l) {
             src[n] = Wh[l]; dst[n] = base + l * wsz; cols[n] = H; mode[n] = pass; ++n;
             if (l > 0) { src[n] = Wx[l]; dst[n] = base + (L + l - 1) * wsz; cols[n] = H; mode[n] = pass; ++n; }
@@ -1870,19 +1872,26 @@ extern "C" int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L) { retur
 // sync_ws[500] != 0 means a block gave up waiting (results invalid: fall back to arcvae_enc_lstm_forward).
 extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                                   const float* const* Wh, const float* const* bias, float* hseq,
-                                                  float* cseq, float* gseq, float* wt, float* wT_bwd,
-                                                  unsigned* sync_ws, unsigned* start_signal, int B, int T, int V,
-                                                  int H, int L, unsigned long long* trace, hipStream_t stream) {
-    if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq || !wt || !sync_ws) return ARCVAE_ERR_ARG;
+                                                  float* cseq, float* gseq, float* wT_bwd, unsigned* sync_ws,
+                                                  unsigned* start_signal, int B, int T, int V, int H, int L, int flags,
+                                                  unsigned long long* trace, hipStream_t stream) {
+    if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq || !sync_ws) return ARCVAE_ERR_ARG;
     if (V <= 0 || !persist_shape_ok(B, T, H, L)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
-    int rc = tile_all_weights(Wx, Wh, wt, wT_bwd, H, L, stream);
-    if (rc != ARCVAE_OK) return rc;
-    rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS, PS_WORDS, stream);
-    if (rc != ARCVAE_OK) return rc;
+    int rc;
+    if (wT_bwd) {      // BPTT layouts for a launch-based backward of the same step (the sweep itself reads row-major weights)
+        rc = tile_all_weights(Wx, Wh, nullptr, wT_bwd, H, L, stream);
+        if (rc != ARCVAE_OK) return rc;
+    }
+    if (!(flags & 1)) {   // bit 0: sync_ws was re-armed by arcvae_enc_prologue
+        rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS, PS_WORDS, stream);
+        if (rc != ARCVAE_OK) return rc;
+    }
     PersistArgs a;
-    a.x_tb = x_tb; a.table0 = table0; a.wt = wt; a.hseq = hseq; a.cseq = cseq; a.gseq = gseq;
+    a.x_tb = x_tb; a.table0 = table0; a.hseq = hseq; a.cseq = cseq; a.gseq = gseq;
+    for (int i = 0; i < 7; ++i) a.W[i] = Wh[0];
+    for (int l = 0; l < L; ++l) { a.W[l] = Wh[l]; if (l > 0) a.W[L + l - 1] = Wx[l]; }
     for (int l = 0; l < ARCVAE_MAX_LAYERS; ++l) a.bias[l] = (l > 0 && l < L) ? bias[l] : nullptr;
     a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace;
     a.B = B; a.T = T; a.H = H; a.V = V; a.RX = ceil_div(B, 8); a.prio = arcvae_step_prio();

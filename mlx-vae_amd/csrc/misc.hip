@@ -381,6 +381,37 @@ extern "C" int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw,
     return arcvae_launch_status();
 }
 
+// ---- the byte-moving launches in front of the persistent forward sweep as ONE (round 2: token transpose, gradient
+// memset and the sweep's re-arm were three launch-bound kernels of ~3-5 us each between the optimizer step and the
+// first tick; the table0 product stays a skinny MFMA GEMM -- a per-thread dot-product form of it, tried here first,
+// took ~70 us on uncoalesced weight rows) -----------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __restrict__ x_bt, int32_t* x_tb, int B, int T,
+                                                           float4* zero, long nz4, unsigned* sync, int nsync) {
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x, gs = (long)gridDim.x * 256;
+    for (long i = gt; i < (long)B * T; i += gs) {
+        const int t = (int)(i / B), bb = (int)(i % B);
+        x_tb[i] = x_bt[(long)bb * T + t];
+    }
+    for (long i = gt; i < nsync; i += gs) sync[i] = 0u;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = gt; i < nz4; i += gs) zero[i] = z;
+}
+}  // namespace
+
+// x_bt [B,T] -> x_tb [T,B];  zero_f32 (optional, 16-byte aligned, n_zero % 4 == 0) = 0;  sync_ws[0 .. n_sync) = 0
+// (optional).  Replaces arcvae_transpose_tokens + the gradient memset + the sweep's re-arm in front of
+// arcvae_enc_lstm_forward_persistent(flags & 1).
+extern "C" int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, unsigned* sync_ws,
+                                   int n_sync, int B, int T, hipStream_t stream) {
+    if (!x_bt || !x_tb || B <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    if (zero_f32 && ((n_zero % 4) != 0 || (reinterpret_cast<uintptr_t>(zero_f32) & 15) != 0)) return ARCVAE_ERR_ARG;
+    if (n_sync < 0 || (n_sync > 0 && !sync_ws)) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(enc_prologue_kernel, dim3(256), dim3(256), 0, stream, x_bt, x_tb, B, T,
+                       reinterpret_cast<float4*>(zero_f32), zero_f32 ? n_zero / 4 : 0L, sync_ws, n_sync);
+    return arcvae_launch_status();
+}
+
 extern "C" int arcvae_transpose_tokens(const int32_t* src, int32_t* dst, int B, int T, hipStream_t stream) {
     if (!src || !dst || B <= 0 || T <= 0) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(transpose_tokens_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, stream, src, dst, B, T);
