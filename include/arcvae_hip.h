@@ -110,10 +110,10 @@ int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, co
                                         float* dG, float* dcs, float* dxs, const float* wT, unsigned* sync_ws,
                                         unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
                                         int chunk_index, unsigned long long* trace, arcvae_stream_t stream);
-/* Reduce-scatter form of the persistent BPTT sweep (H = 256, L <= 2, B <= 64): a CU keeps the gate gradients of its own
+/* Reduce-scatter form of the persistent BPTT sweep (H = 256, L <= 2, B <= 256): a CU keeps the gate gradients of its own
  * 32 gate columns on chip, multiplies them with its 32 rows of the row-major Wh / Wx, and the partial sums are
- * reduce-scattered through the XCD's L2 (part_ws: 2*(2L-1)*8*32*32*64 floats).  Otherwise as
- * arcvae_enc_lstm_backward_persistent. */
+ * reduce-scattered through the XCD's L2 (part_ws: RG*2*(2L-1)*8*32*32*64 floats, RG = 1 / 2 / 4 groups of 8 rows per
+ * XCD for B <= 64 / 128 / 256).  Otherwise as arcvae_enc_lstm_backward_persistent. */
 int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
                                            const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,

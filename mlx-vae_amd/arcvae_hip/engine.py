@@ -120,8 +120,9 @@ class Workspace:
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
             self.dtable0 = torch.empty(V, G, **f32)
             self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)
-            if H == 256 and L <= 2 and B <= 64:   # partial sums in flight of the reduce-scatter BPTT sweep (12.6 MB)
-                self.ppart = torch.empty(2 * (2 * L - 1) * 8 * 32 * 32 * 64, **f32)
+            if H == 256 and L <= 2 and B <= 256:  # partial sums in flight of the reduce-scatter BPTT sweep (12.6 MB per
+                rg = 1 if B <= 64 else (2 if B <= 128 else 4)   # group of 8 rows per XCD)
+                self.ppart = torch.empty(rg * 2 * (2 * L - 1) * 8 * 32 * 32 * 64, **f32)
             self.dlogits = torch.empty(BV, V, **f32)
             self.ddh = torch.empty(2, BV, H, **f32)
             self.ddG = torch.empty(BV, G, **f32)
@@ -446,6 +447,12 @@ class EncoderBackwardPlan:
                      ptr(enc.p("embedding.weight")), ptr(enc.g("embedding.weight")), ptr(enc.g("lstm_layer_0.Wx")),
                      ptr(enc.g("lstm_layer_0.bias")), d.V, d.E, 4 * d.H, stream_ptr())
             return
+        if not (self.persistent and ws.B <= 64):
+            # The split-bf16 GEMM pays beside the one-row-group persistent sweep only (1.061 vs 1.083 ms at bs 64: its
+            # 208 registers fit on a SIMD next to the sweep's 296, and it leaves the matrix pipe to the chain).  Beside
+            # the 2-group sweep (343 registers) it cannot be resident, and beside the per-step launches the exact-f32
+            # tile GEMM is the faster one (bs 256: 3.254 vs 3.363 ms).
+            parts |= 16
         call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
              ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(ws.onehot), ptr(enc.g("embedding.weight")), self._dwx[0],
              self._dwh[0],

@@ -557,9 +557,10 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
 // atomics (split-K inside each problem).  Internal (ops.h); falls back to n single launches when the operands do
 // not allow the 16-byte path.
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
-                               const float* const* B, int ldb, float* const* C, int ldc, hipStream_t stream) {
+                               const float* const* B, int ldb, float* const* C, int ldc, bool allow_split,
+                               hipStream_t stream) {
     if (n <= 0 || n > ARCVAE_GEMM_GROUP_MAX || M <= 0 || N <= 0) return ARCVAE_ERR_ARG;
-    {
+    if (allow_split) {
         bool ok = true;
         for (int i = 0; i < n; ++i) ok = ok && K[i] > 0 && split_tn_ok(M, N, A[i], lda, B[i], ldb);
         if (ok) {

@@ -1362,17 +1362,23 @@ struct PersistRsArgs {
 // registers per lane over the whole sweep and added to the gradient buffers once, at the end (8 XCDs x 3 sources:
 // float atomics, full 128-B rows).  The token-table gradient (layer 0's input side) is an LDS scatter-add by token, the
 // bias gradient a per-thread running sum.  No aux-stream GEMMs, no chunks, nothing beside the sweep.
-template <int LL, bool WR, int MF, bool FW = false>   // WR: the weight slices live in registers, else in LDS
+// RG = groups of 8 rows per XCD (rows per XCD RX <= 8 RG: B <= 64 RG; round 2: RG = 2, 4 for 65..256 rows per GPU, e.g.
+// the 256-row shard of BASELINE.json configs[3]): a tick walks the groups -- products and partial stores of every
+// group, ONE store wait / flag / barrier, then gather and epilogue of every group -- so the per-tick exchange cost is
+// paid once for up to 32 rows.
+template <int LL, bool WR, int MF, bool FW = false, int RG = 1>   // WR: the weight slices live in registers, else in LDS
 __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
     static_assert(MF == 0 || WR, "the 4x4x1 form keeps its weights in registers");
     static_assert(!FW || MF == 1, "fused weight gradients: 4x4x1 form only");
+    static_assert(RG == 1 || (MF == 1 && !FW), "row groups: 4x4x1 form, weight gradients by GEMM");
+    constexpr int DGL = LL * 16 * 32;                 // floats of one group's gate-gradient image
     const PersistBwdArgs& a = ar.b;
     constexpr int UW = 8, S = 2 * LL - 1, WS = 36;   // WS: padded row stride of the weight image (bank-conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wloc = lds;                                // [S][256 units][WS]: W[my gate col k][unit], k-contiguous (LDS variant)
     float* dgl = wloc + (WR ? 0 : S * 256 * WS);      // [LL][16 rows][32 gate cols of mine]  (rows >= 8 stay zero)
-    float* dxl = dgl + LL * 16 * 32;                  // [2][64]
-    float* dtl = dxl + 128;                           // FW: [V][33] token-table gradient of my 32 gate columns
+    float* dxl = dgl + RG * DGL;                      // [RG][2][64]
+    float* dtl = dxl + RG * 128;                           // FW: [V][33] token-table gradient of my 32 gate columns
     __shared__ unsigned s_role, s_xcc, s_ok;
     arcvae_set_prio(a.prio);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1430,7 +1436,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                 *reinterpret_cast<f32x4*>(wloc + (si * 256 + tid) * WS + k) = f32x4{wv[k], wv[k + 1], wv[k + 2], wv[k + 3]};
         }
     }
-    for (int i = tid; i < LL * 16 * 32; i += 256) dgl[i] = 0.f;
+    for (int i = tid; i < RG * DGL; i += 256) dgl[i] = 0.f;
     if constexpr (FW)
         for (int i = tid; i < ar.V * 33; i += 256) dtl[i] = 0.f;   // row stride 33: rows of different tokens on different banks
     __syncthreads();
@@ -1495,10 +1501,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
     const bool is_cell = slot < LL;
     const int el = is_cell ? (LL - 1 - slot) : (slot - LL);
     const int erow = p >> 3, ul = p & 7;
-    const bool eact = slot < S && erow < RX && row0 + erow < B;
-    const int eb = min(row0 + erow, B - 1), unit = role * UW + ul;
-    const long hb = (long)eb * H + unit;
-    float dcst = 0.f;
+    const int unit = role * UW + ul;
+    bool eact[RG];
+    int eb[RG];
+    long hb[RG];
+    float dcst[RG];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+        eact[g] = slot < S && 8 * g + erow < RX && row0 + 8 * g + erow < B;
+        eb[g] = min(row0 + 8 * g + erow, B - 1);
+        hb[g] = (long)eb[g] * H + unit;
+        dcst[g] = 0.f;
+    }
     unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
     const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
     const long part_src = (long)8 * 32 * 32 * 64;     // floats per (parity, source)
@@ -1508,38 +1522,45 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         const int t = is_cell ? T - 1 - (s - skew) : T - 1 - (s + 1 - skew);
         const bool jact = slot < S && t >= 0 && t < T;
         // forward values of my epilogue (static) -- requested first
-        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c_v = 0.f, cprev_v = 0.f, ext_v = 0.f;
-        if (eact && is_cell && jact) {
-            const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb * G + unit;
-            gi = gp[0]; gf = gp[H]; gg = gp[2 * H]; go = gp[3 * H];
-            c_v = a.cseq[el * lH + (long)t * sH + hb];
-            if (t > 0) cprev_v = a.cseq[el * lH + (long)(t - 1) * sH + hb];
-            if (el == LL - 1 && t == T - 1) ext_v = a.dh_top[(long)eb * a.ld_dh_top + unit];
-            if (s == a.s_begin) {
-                dcst = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb] : 0.f;
-                if (el < LL - 1) ext_v = a.dxs[((long)el * RS + (t % RS)) * sH + hb];
+        float gi[RG], gf[RG], gg[RG], go[RG], c_v[RG], cprev_v[RG], ext_v[RG];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            gi[g] = gf[g] = gg[g] = go[g] = c_v[g] = cprev_v[g] = ext_v[g] = 0.f;
+            if (eact[g] && is_cell && jact) {
+                const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb[g] * G + unit;
+                gi[g] = gp[0]; gf[g] = gp[H]; gg[g] = gp[2 * H]; go[g] = gp[3 * H];
+                c_v[g] = a.cseq[el * lH + (long)t * sH + hb[g]];
+                if (t > 0) cprev_v[g] = a.cseq[el * lH + (long)(t - 1) * sH + hb[g]];
+                if (el == LL - 1 && t == T - 1) ext_v[g] = a.dh_top[(long)eb[g] * a.ld_dh_top + unit];
+                if (s == a.s_begin) {
+                    dcst[g] = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb[g]] : 0.f;
+                    if (el < LL - 1) ext_v[g] = a.dxs[((long)el * RS + (t % RS)) * sH + hb[g]];
+                }
             }
         }
         int tok = 0;
         if constexpr (FW) {
-            if (eact && is_cell && jact && el == 0) tok = min(max(ar.x_tb[(long)t * B + eb], 0), ar.V - 1);
+            if (eact[0] && is_cell && jact && el == 0) tok = min(max(ar.x_tb[(long)t * B + eb[0]], 0), ar.V - 1);
         }
         // first tick of a chunk: my gate columns of the gradients the previous chunk left in memory
         if (s == a.s_begin) {
-            for (int i = tid; i < LL * 8 * 32; i += 256) {
-                const int l = i / 256, rem = i - l * 256, rw = rem >> 5, k = rem & 31;
+            for (int i = tid; i < RG * LL * 8 * 32; i += 256) {
+                const int g = i / (LL * 256), ig = i - g * (LL * 256);
+                const int l = ig / 256, rem = ig - l * 256, rw = rem >> 5, k = rem & 31;
                 const int tl_ = T - 1 - (s - 2 * (LL - 1 - l));          // cell(l, tl_) of this tick reads dG^l_{tl_ + 1}
                 float v = 0.f;
-                if (tl_ + 1 >= 0 && tl_ + 1 < T && rw < RX && row0 + rw < B)
-                    v = a.dG[l * lG + (long)(tl_ + 1) * sG + (long)(row0 + rw) * G + (k >> 3) * H + role * UW + (k & 7)];
-                dgl[(l * 16 + rw) * 32 + k] = v;
+                if (tl_ + 1 >= 0 && tl_ + 1 < T && 8 * g + rw < RX && row0 + 8 * g + rw < B)
+                    v = a.dG[l * lG + (long)(tl_ + 1) * sG + (long)(row0 + 8 * g + rw) * G + (k >> 3) * H + role * UW + (k & 7)];
+                dgl[g * DGL + (l * 16 + rw) * 32 + k] = v;
             }
             __syncthreads();
         }
         if (s > a.s_begin) wg_prepare(s - 1, 0, 2);   // FW (sources 0, 1; source 2 behind the flag store): operands of the weight-gradient products of the previous tick's gate gradients
         if (tr) a.trace[2 * s] = wall_clock64();
         // ---- partial products of the S slots from my local gate gradients; wave w covers units [64w, 64w + 64)
-        float* pbase = ar.part + (long)(s & 1) * S * part_src + (long)xcc * 32 * 32 * 64;
+        float* pbase = ar.part + (long)(s & 1) * S * part_src + (long)xcc * 32 * 32 * 64;   // group g: + g * 2 S part_src
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             const bool cellj = j < LL;
@@ -1550,12 +1571,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             const int ls = cellj ? lj : lj + 1;                         // layer whose local gradients feed this slot
             if constexpr (MF == 1) {
                 // lane (rg, ug, ij): row 4rg + ij, units ju0 .. ju0+3 -> consumer ju0>>3, piece [row][ju0&7 ..]
-                float* pdst = pbase + j * part_src + ((long)((64 * wave + 4 * ug) >> 3) * 32 + role) * 64 + (4 * rg + ij) * 8 + ((4 * ug) & 7);
+                float* pdst = pbase + (long)g * 2 * S * part_src + j * part_src + ((long)((64 * wave + 4 * ug) >> 3) * 32 + role) * 64 + (4 * rg + ij) * 8 + ((4 * ug) & 7);
                 if (actj) {
                     f32x4 bq[8];
 #pragma unroll
                     for (int k4 = 0; k4 < 8; ++k4)
-                        bq[k4] = *reinterpret_cast<const f32x4*>(dgl + (ls * 16 + 4 * rg + ij) * 32 + 4 * k4);
+                        bq[k4] = *reinterpret_cast<const f32x4*>(dgl + g * DGL + (ls * 16 + 4 * rg + ij) * 32 + 4 * k4);
                     f32x4 acc[2][2];      // two independent chains per unit chunk (first link: C = 0)
 #pragma unroll
                     for (int k4 = 0; k4 < 8; ++k4)
@@ -1633,44 +1654,47 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         }
         __syncthreads();
         if (!s_ok) return;
-        // ---- gather: the 32 pieces of my (slot, row, unit)
+        // ---- gather: the 32 pieces of my (slot, row, unit), group by group, then that group's epilogue
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
         float dh = 0.f;
         {
             // my role's 32 pieces of this slot: 8 KB contiguous, [producer][64 (row, unit) values]
             // (slot = tid >> 6 is wave-uniform: say so, or the compiler wraps every load in a waterfall loop over the
             // descriptor's lanes with a vmcnt(0) inside -- 32 serialised round trips)
             const int slot_u = __builtin_amdgcn_readfirstlane(slot);
-            const __amdgpu_buffer_rsrc_t rs = ps_rsrc(pbase + (slot_u < S ? slot_u : 0) * part_src + ((long)role * 32) * 64, 32 * 64 * 4);
+            const __amdgpu_buffer_rsrc_t rs = ps_rsrc(pbase + (long)g * 2 * S * part_src + (slot_u < S ? slot_u : 0) * part_src + ((long)role * 32) * 64, 32 * 64 * 4);
             float v[32];
-            const bool gact = eact && jact;
+            const bool gact = eact[g] && jact;
             if (gact) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) v[i] = ps_load_sc1(rs, (unsigned)((i * 64 + p) * 4));
             }
-            if constexpr (LL > 1) wg_mfma(2);   // FW: the rest of the weight-gradient products, under the gather's loads
+            if constexpr (LL > 1) { if (g == 0) wg_mfma(2); }   // FW: the rest of the weight-gradient products, under the gather's loads
             if (gact) {
 #pragma unroll
                 for (int i = 0; i < 32; i += 4) dh += (v[i] + v[i + 1]) + (v[i + 2] + v[i + 3]);
             }
         }
-        if (eact && jact) {
+        float* dxg = dxl + g * 128;
+        if (eact[g] && jact) {
             if (!is_cell) {
-                dxl[((s + 1) & 1) * 64 + p] = dh;
-                a.dxs[((long)el * RS + (t % RS)) * sH + hb] = dh;
+                dxg[((s + 1) & 1) * 64 + p] = dh;
+                a.dxs[((long)el * RS + (t % RS)) * sH + hb[g]] = dh;
             } else {
-                if (el < LL - 1 && s != a.s_begin) ext_v = dxl[(s & 1) * 64 + p];
-                dh += ext_v;
-                const float tc = chain_tanh(c_v);
-                const float d_o = dh * tc * go * (1.f - go);
-                const float dc = dh * go * (1.f - tc * tc) + dcst;
-                const float d_i = dc * gg * gi * (1.f - gi);
-                const float d_f = t > 0 ? dc * cprev_v * gf * (1.f - gf) : 0.f;
-                const float d_g = dc * gi * (1.f - gg * gg);
-                dcst = dc * gf;
-                a.dcs[((long)el * RS + (t % RS)) * sH + hb] = dcst;
-                float* dp = a.dG + el * lG + (long)t * sG + (long)eb * G + unit;
+                if (el < LL - 1 && s != a.s_begin) ext_v[g] = dxg[(s & 1) * 64 + p];
+                dh += ext_v[g];
+                const float tc = chain_tanh(c_v[g]);
+                const float d_o = dh * tc * go[g] * (1.f - go[g]);
+                const float dc = dh * go[g] * (1.f - tc * tc) + dcst[g];
+                const float d_i = dc * gg[g] * gi[g] * (1.f - gi[g]);
+                const float d_f = t > 0 ? dc * cprev_v[g] * gf[g] * (1.f - gf[g]) : 0.f;
+                const float d_g = dc * gi[g] * (1.f - gg[g] * gg[g]);
+                dcst[g] = dc * gf[g];
+                a.dcs[((long)el * RS + (t % RS)) * sH + hb[g]] = dcst[g];
+                float* dp = a.dG + el * lG + (long)t * sG + (long)eb[g] * G + unit;
                 dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
-                float* dl = dgl + (el * 16 + erow) * 32 + ul;        // my gate columns stay on the CU for the next tick
+                float* dl = dgl + g * DGL + (el * 16 + erow) * 32 + ul;   // my gate columns stay on the CU for the next tick
                 dl[0] = d_i; dl[8] = d_f; dl[16] = d_g; dl[24] = d_o;
                 if constexpr (FW) {
                     if (el > 0) {                                    // bias gradient of the layers above 0: running sum
@@ -1681,6 +1705,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                     }
                 }
             }
+        }
         }
         __syncthreads();
         if (tr) a.trace[2 * s + 1] = wall_clock64();
@@ -1952,12 +1977,14 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
 
 // 1 if arcvae_enc_lstm_backward_persistent_rs supports the shape (and ARCVAE_PERSIST != 0).
 extern "C" int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L) {
-    return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && H == 256 && L >= 1 && L <= 2 && B >= 1 && B <= 64 && T >= 1) ? 1 : 0;
+    // ARCVAE_RS_MAX_B
+    return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && H == 256 && L >= 1 && L <= 2 && B >= 1 &&
+            B <= arcvae_env_int("ARCVAE_RS_MAX_B", 128) && B <= 256 && T >= 1) ? 1 : 0;
 }
 
-// Reduce-scatter form of the persistent BPTT sweep (lstm_bwd_persist_rs_kernel): H = 256, L <= 2, B <= 64.
-//   Wx / Wh: HOST arrays of the row-major weights (as arcvae_enc_lstm_backward);  part_ws: 2 * (2L-1) * 8 * 32 * 32 * 64
-//   floats of scratch for the partial sums in flight.  Everything else as arcvae_enc_lstm_backward_persistent.
+// Reduce-scatter form of the persistent BPTT sweep (lstm_bwd_persist_rs_kernel): H = 256, L <= 2, B <= 256.
+//   Wx / Wh: HOST arrays of the row-major weights (as arcvae_enc_lstm_backward);  part_ws: RG * 2 * (2L-1) * 8 * 32 * 32 * 64
+//   floats of scratch for the partial sums in flight, RG = 1 / 2 / 4 for B <= 64 / 128 / 256.  Everything else as arcvae_enc_lstm_backward_persistent.
 // fused != null: the FW variant (weight gradients accumulated in the kernel, see lstm_bwd_persist_rs_kernel).
 namespace {
 struct FusedWgrad {
@@ -1968,8 +1995,11 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
                   unsigned* sync_ws, unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
                   int chunk_index, unsigned long long* trace, const FusedWgrad* fused, hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !part_ws || !sync_ws) return ARCVAE_ERR_ARG;
-    if (H != 256 || L < 1 || L > 2 || B < 1 || B > 64 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
+    if (H != 256 || L < 1 || L > 2 || B < 1 || B > 256 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
+    const int rows_x = ceil_div(B, 8);                                  // rows per XCD
+    const int rgn = rows_x <= 8 ? 1 : (rows_x <= 16 ? 2 : 4);            // groups of 8 rows a tick walks
+    if (fused && rgn != 1) return ARCVAE_ERR_ARG;
     const int S = T + 2 * (L - 1);
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
@@ -2006,16 +2036,20 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
         }
     }
     // ARCVAE_RS_WREG=0: weight slices in LDS instead of registers.  Either way at least 81 KB of LDS: one block per CU.
-    const bool wreg = arcvae_env_int("ARCVAE_RS_WREG", 1) != 0 || fused;
-    size_t lds = sizeof(float) * ((wreg ? 0 : (size_t)(2 * L - 1) * 256 * 36) + (size_t)L * 16 * 32 + 128 + (fused ? 128 * 33 : 0));
+    const bool wreg = arcvae_env_int("ARCVAE_RS_WREG", 1) != 0 || fused || rgn > 1;
+    size_t lds = sizeof(float) * ((wreg ? 0 : (size_t)(2 * L - 1) * 256 * 36) + (size_t)rgn * (L * 16 * 32 + 128) + (fused ? 128 * 33 : 0));
     if (lds < persist_lds_floor()) lds = persist_lds_floor();
     auto launch = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, stream, ar);
     };
     // ARCVAE_RS_MFMA: 1 (default) = 4x4x1 blocks, 0 = 16x16x4 tiles (registers only; the LDS variant always uses 16x16x4)
-    const bool mf = (wreg && arcvae_env_int("ARCVAE_RS_MFMA", 1) != 0) || fused;
-    if (L == 1) {
+    const bool mf = (wreg && arcvae_env_int("ARCVAE_RS_MFMA", 1) != 0) || fused || rgn > 1;
+    if (rgn == 2) {
+        if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 1, false, 2>); else launch(lstm_bwd_persist_rs_kernel<2, true, 1, false, 2>);
+    } else if (rgn == 4) {
+        if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 1, false, 4>); else launch(lstm_bwd_persist_rs_kernel<2, true, 1, false, 4>);
+    } else if (L == 1) {
         if (fused) launch(lstm_bwd_persist_rs_kernel<1, true, 1, true>);
         else if (mf) launch(lstm_bwd_persist_rs_kernel<1, true, 1>);
         else if (wreg) launch(lstm_bwd_persist_rs_kernel<1, true, 0>);
@@ -2161,7 +2195,9 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   l == 0: dTable0[v] += sum_{(t,b): x=v} dG_0[t,b]   (dtable_ws [V,4H], zeroed when `first` != 0)
 //   when `last` != 0 (all ranges done): dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;  dbias_0 += colsum(dTable0)
 //   parts: bit 0 = the per-layer GEMMs (= bits 2 | 3), bit 1 = the layer-0 token-table path, bit 2 = only the dWx_l
-//   GEMMs (l >= 1) and the bias column sums, bit 3 = only the dWh_l GEMMs (disjoint outputs: up to three streams)
+//   GEMMs (l >= 1) and the bias column sums, bit 3 = only the dWh_l GEMMs (disjoint outputs: up to three streams);
+//   bit 4 = exact-f32 MFMA tile GEMMs instead of the split-bf16 kernel (45 instead of 208 registers per lane: what
+//   fits on a SIMD beside a persistent sweep wave of more than 296 registers, i.e. the 2 / 4 row-group sweeps)
 //   onehot_ws [T*B, roundup(V,4)] workspace: one-hot token rows, written when `first` != 0 (token-table part)
 extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0,
                                      const float* hseq, const float* dG, float* dtable_ws, float* onehot_ws,
@@ -2175,6 +2211,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     const long lH = (long)TB * H, lG = (long)TB * G;
     int rc;
     const bool do_wx = (parts & (1 | 4)) != 0, do_wh = (parts & (1 | 8)) != 0, do_table = (parts & 2) != 0;
+    const bool exact_f32 = (parts & 16) != 0;
     const bool do_layers = do_wx || do_wh;
     const int Vp = (V + 3) & ~3;
     if (do_table && first) {
@@ -2205,7 +2242,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
             }
             for (int i = 0; i < n; i += 8) {
                 rc = arcvae_gemm_tn_group_accum(n - i < 8 ? n - i : 8, G, H, Kg + i, Ag + i, G, Bg + i, H, Cg + i, H,
-                                                stream);
+                                                !exact_f32, stream);
                 if (rc) return rc;
             }
             for (int l = 1; l < L && do_wx; ++l) {
@@ -2215,7 +2252,8 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
         }
         if (do_table) {  // dTable0 += OneHot[rows]^T . dG_0[rows]   (see onehot_kernel)
             rc = arcvae_gemm_f32(1, 0, V, G, nt * B, onehot_ws + (long)t_lo * B * Vp, Vp, dG + (long)t_lo * B * G, G,
-                                 dtable_ws, G, nullptr, ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK, stream);
+                                 dtable_ws, G, nullptr,
+                                 ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | (exact_f32 ? ARCVAE_GEMM_TILE64 : 0), stream);
             if (rc) return rc;
         }
     }

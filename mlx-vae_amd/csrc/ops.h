@@ -14,7 +14,8 @@
 
 // internal (C++ linkage): grouped weight-gradient GEMMs, see gemm.hip
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
-                               const float* const* B, int ldb, float* const* C, int ldc, hipStream_t stream);
+                               const float* const* B, int ldb, float* const* C, int ldc, bool allow_split,
+                               hipStream_t stream);
 
 extern "C" {
 int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
