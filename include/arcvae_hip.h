@@ -97,14 +97,18 @@ int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L);
  * re-armed by arcvae_enc_prologue.) */
 int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
-                                       float* gseq, float* wT_bwd, unsigned* sync_ws, unsigned* start_signal,
-                                       int B, int T, int V, int H, int L, int flags, unsigned long long* trace,
-                                       arcvae_stream_t stream);
+                                       float* gseq, float* wT_bwd, float* comb /* optional [B,2H]: its first H columns
+                                       receive h_{T-1} of the top layer, the heads' input (models/encoder.py:106) */,
+                                       unsigned* sync_ws, unsigned* start_signal, int B, int T, int V, int H, int L,
+                                       int flags, unsigned long long* trace, arcvae_stream_t stream);
 /* The byte-moving launches in front of the persistent forward sweep as one: x_tb = x_bt^T (arcvae_transpose_tokens),
  * zero_f32[0..n_zero) = 0 (optional: the encoder's gradient buffer), sync_ws[0..n_sync) = 0 (optional: the sweep's
  * re-arm). */
+/* cond .. stats (optional, all or none): also comb[:, H:2H] = condition_fc(cond) (models/encoder.py:109-112) and
+ * stats[0..n_stats) = 0, for arcvae_enc_heads_forward(comb_ready = 1). */
 int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, unsigned* sync_ws, int n_sync,
-                        int B, int T, arcvae_stream_t stream);
+                        const float* cond, const float* Wc, const float* bc, float* comb, float* stats, int n_stats,
+                        int B, int T, int H, int C, arcvae_stream_t stream);
 int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, const float* dh_top, int ld_dh_top,
                                         float* dG, float* dcs, float* dxs, const float* wT, unsigned* sync_ws,
@@ -148,12 +152,14 @@ int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx
 /* ---- encoder heads + reparameterisation + latent loss ----------------------------------------
  * models/encoder.py:106-130 (condition_fc, fc_mu, fc_logvar_hidden, fc_logvar, tanh bounds),
  * models/encoder.py:147-153 (z = mu + eps*exp(logvar/2), eps injected), and the per-rank halves
- * of losses/kl.py:39-56 and losses/info.py:27-41.  stats [2Z+4] is zeroed and filled here. */
+ * of losses/kl.py:39-56 and losses/info.py:27-41.  stats [2Z+4] is zeroed and filled here.
+ * comb_ready != 0: comb [B,2H] and the zeroed stats were written ahead of the call (arcvae_enc_prologue + the persistent
+ * forward sweep): hT, cond, Wc, bc are not read. */
 int arcvae_enc_heads_forward(const float* hT, const float* cond, const float* Wc, const float* bc,
                              const float* Wmu, const float* bmu, const float* Wlh, const float* blh,
                              const float* Wlv, const float* blv, const float* eps, float* comb, float* lh,
                              float* mu_raw, float* lv_raw, float* mu, float* logvar, float* z, float* stats,
-                             int B, int H, int Z, int C, float free_bits, arcvae_stream_t stream);
+                             int B, int H, int Z, int C, float free_bits, int comb_ready, arcvae_stream_t stream);
 int arcvae_stats_set_recon(const float* rowloss, int B, float* stats, int Z, arcvae_stream_t stream);
 /* complete_vae_loss.py:45-99 (+ losses/kl.py, losses/info.py reductions) from GLOBAL stats.
  * hyper [8] device: beta, lambda_collapse, lambda_mi, target_mi, free_bits; scalars [16] device out:

@@ -34,8 +34,8 @@ SIGNATURES = {
     "arcvae_transpose_tokens": [_vp, _vp, _i, _i, _vp],
     "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_persistent_ok": [_i, _i, _i, _i],
-    "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "arcvae_enc_prologue": [_vp, _vp, _vp, _l, _vp, _i, _i, _i, _vp],
+    "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_prologue": [_vp, _vp, _vp, _l, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "arcvae_enc_lstm_bwd_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_rs_ok": [_i, _i, _i, _i],
@@ -44,7 +44,7 @@ SIGNATURES = {
                                        _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _vp],
+    "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _i, _vp],
     "arcvae_stats_set_recon": [_vp, _i, _vp, _i, _vp],
     "arcvae_latent_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "arcvae_loss_finalize": [_vp, _vp, _i, _i, _vp, _vp, _vp],

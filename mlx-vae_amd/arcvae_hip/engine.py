@@ -175,16 +175,21 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         # Two launches in front of the sweep instead of six: [tokens^T + the gradient buffer's zero fill + the sweep's
         # re-arm] and table0 = embedding . Wx_0^T + bias_0 ([V,4H]: the layer-0 input projection of every token).  The
         # sweep reads the row-major weights itself; k-chunk-major BPTT copies are only written for a launch-based backward.
+        # The prologue also writes the condition half of the heads' input and clears `stats`; the sweep's last tick stores
+        # h_{T-1} of the top layer into the other half: the heads start without a build launch.
         grad = enc.grad if zero_grad else None
         call("arcvae_enc_prologue", ptr(ws.x), ptr(ws.x_tb), ptr(grad), C.c_long(grad.numel() if grad is not None else 0),
-             ptr(ws.psync), 272, B, T, s)
+             ptr(ws.psync), 272, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
+             ptr(ws.comb), ptr(ws.stats), 2 * d.Z + 4, B, T, d.H, d.C, s)
+        comb_ready = 1
         call("arcvae_gemm_f32", 0, 1, d.V, G, d.E, ptr(enc.p("embedding.weight")), d.E,
              ptr(enc.p("lstm_layer_0.Wx")), d.E, ptr(ws.table0), G, ptr(enc.p("lstm_layer_0.bias")), 0, s)
         need_wT = hasattr(ws, "wT") and not bptt_reduce_scatter_ok(ws, d)
         call("arcvae_enc_lstm_forward_persistent", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq),
-             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wT) if need_wT else C.c_void_p(0), ptr(ws.psync),
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wT) if need_wT else C.c_void_p(0), ptr(ws.comb), ptr(ws.psync),
              start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L, 1, ptr(ws.trace_fwd), s)
     else:
+        comb_ready = 0
         if zero_grad:
             enc.grad.zero_()
         call("arcvae_transpose_tokens", ptr(ws.x), ptr(ws.x_tb), B, T, s)
@@ -202,7 +207,7 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
          ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar_hidden.bias")),
          ptr(enc.p("fc_logvar.weight")), ptr(enc.p("fc_logvar.bias")), ptr(ws.eps), ptr(ws.comb), ptr(ws.lh),
          ptr(ws.mu_raw), ptr(ws.lv_raw), ptr(ws.mu), ptr(ws.logvar), ptr(ws.z), ptr(ws.stats), B, d.H, d.Z,
-         d.C, float(free_bits), s)
+         d.C, float(free_bits), comb_ready, s)
 
 
 def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: int = 0,

@@ -463,6 +463,41 @@ int launch_split_tn_group(int n, const SplitTN* probs, hipStream_t stream) {
     return arcvae_launch_status();
 }
 
+// Two independent skinny problems of the same layout in ONE launch (blockIdx.x walks the column tiles of the first, then
+// of the second): the encoder heads' pairs [mu_raw | tanh(lh)] and [dcomb | dlh] sit on the step's critical chain, where
+// every launch is a ~6 us seam.
+struct GemmPair { GemmP p[2]; int nx0; };
+template <bool BKC>
+__global__ __launch_bounds__(256) void gemm_skinny_pair_kernel(GemmPair g) {
+    __shared__ float red[4 * 256];
+    const int which = (int)blockIdx.x >= g.nx0 ? 1 : 0;
+    const GemmP& p = g.p[which];
+    const int bx = (int)blockIdx.x - (which ? g.nx0 : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 16, n0 = bx * 16;
+    if (m0 >= p.M || n0 >= p.N) return;
+    const int arow = min(m0 + (lane & 15), p.M - 1);
+    const int bcol = min(n0 + (lane & 15), p.N - 1);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BKC)
+        skinny_accum_kk(acc0, acc1, p.A, (long)arow * p.lda, p.B, (long)bcol * p.ldb, p.K, wave, lane);
+    else
+        skinny_accum_kn(acc0, acc1, p.A, (long)arow * p.lda, p.B, p.ldb, bcol, p.K, wave, lane);
+    skinny_store_partial(red, acc0, acc1, wave, lane);
+    __syncthreads();
+    const int row = tid >> 4, col = tid & 15;
+    const int gr = m0 + row, gc = n0 + col;
+    if (gr < p.M && gc < p.N) {
+        float v = skinny_reduced(red, row, col);
+        if (p.bias && p.act != 2) v += p.bias[gc];
+        float* c = p.C + (long)gr * p.ldc + gc;
+        if (p.accumulate) v += *c;
+        if (p.act == 1) v = tanhf(v);
+        if (p.act == 2) { const float t = p.bias[(long)gr * p.ldc + gc]; v *= (1.0f - t * t); }
+        *c = v;
+    }
+}
+
 template <int BM, int BN, bool AK, bool BKC>
 void launch_tile(const GemmP& p, dim3 grid, bool va4, bool vb4, hipStream_t s) {
     const unsigned pad = arcvae_side_lds_pad(2 * BK * (BM + BN + 2 * PAD) * sizeof(float));
@@ -550,6 +585,32 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     }
     if (big) launch_tile_t<128, 128>(p, grid, ak, bk, va4, vb4, stream);
     else launch_tile_t<64, 64>(p, grid, ak, bk, va4, vb4, stream);
+    return arcvae_launch_status();
+}
+
+// Two skinny products in one launch (internal, ops.h): C_i[M_i,N_i] (+)= A_i[M_i,K_i] . op(B_i) (+ bias_i) (act_i), i = 0, 1;
+// A K-contiguous rows; transB as arcvae_gemm_f32 (the same for both); flags_i: ARCVAE_GEMM_ACCUMULATE / _TANH / _DTANH.
+// Same operand requirements as the skinny path of arcvae_gemm_f32 (K % 64 == 0, 16-byte aligned rows, M <= 256).
+int arcvae_gemm_skinny_pair(int transB, const int* M, const int* N, const int* K, const float* const* A, const int* lda,
+                            const float* const* B, const int* ldb, float* const* C, const int* ldc,
+                            const float* const* bias, const int* flags, hipStream_t stream) {
+    GemmPair g;
+    for (int i = 0; i < 2; ++i) {
+        GemmP& p = g.p[i];
+        if (M[i] <= 0 || N[i] <= 0 || K[i] <= 0 || !A[i] || !B[i] || !C[i] || (K[i] % 64) != 0 || (lda[i] % 4) != 0 || M[i] > 256 ||
+            !aligned16(A[i]) || (transB && ((ldb[i] % 4) != 0 || !aligned16(B[i]))))
+            return ARCVAE_ERR_ARG;
+        p.A = A[i]; p.B = B[i]; p.C = C[i]; p.bias = bias[i];
+        p.M = M[i]; p.N = N[i]; p.K = K[i]; p.lda = lda[i]; p.ldb = ldb[i]; p.ldc = ldc[i];
+        p.accumulate = (flags[i] & ARCVAE_GEMM_ACCUMULATE) ? 1 : 0;
+        p.act = (flags[i] & ARCVAE_GEMM_TANH) ? 1 : ((flags[i] & ARCVAE_GEMM_DTANH) ? 2 : 0);
+        if (p.act == 2 && (!bias[i] || p.accumulate)) return ARCVAE_ERR_ARG;
+        p.kchunk = 0;
+    }
+    g.nx0 = ceil_div(N[0], 16);
+    dim3 grid(g.nx0 + ceil_div(N[1], 16), ceil_div(max(M[0], M[1]), 16), 1);
+    if (transB) hipLaunchKernelGGL(gemm_skinny_pair_kernel<true>, grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(gemm_skinny_pair_kernel<false>, grid, dim3(256), 0, stream, g);
     return arcvae_launch_status();
 }
 

@@ -14,6 +14,7 @@
 // scalars out:  [0] total [1] recon [2] kl [3] beta*kl [4] collapse [5] prop(=0) [6] lambda_prop*prop(=0)
 //               [7] mutual_info [8] mi_penalty [9] d(total)/d(mi_raw) [10] global rows
 #include "ops.h"
+#include "skinny.h"
 
 namespace {
 
@@ -76,6 +77,65 @@ __global__ __launch_bounds__(256) void latent_apply_kernel(const float* __restri
         atomicAdd(stats + 2 * Z, klmi);
         atomicAdd(stats + 2 * Z + 1, klfb);
         atomicAdd(stats + 2 * Z + 2, 1.0f);
+    }
+}
+
+// lv_raw = lh . Wlv^T + blv (a 16 x 16 tile per block, K over the 4 waves: the skinny contraction) with latent_apply as
+// its epilogue: the tile's mu / logvar / z and its share of the batch statistics -- one launch less on the step's
+// critical chain (round 2).  The tile reduces its own sums first: 16 column atomics per quantity and two scalar
+// atomics per block instead of one per element.
+__global__ __launch_bounds__(256) void heads_lv_apply_kernel(const float* __restrict__ lh, const float* __restrict__ Wlv,
+                                                             const float* __restrict__ blv, const float* __restrict__ mu_raw,
+                                                             const float* __restrict__ eps, float* lv_raw, float* mu,
+                                                             float* logvar, float* z, float* stats, int B, int Z, int K,
+                                                             float fb_min) {
+    __shared__ float red[4 * 256];
+    __shared__ float cs[2][16][17];     // per-element terms of the column sums (mu, var)
+    __shared__ float rs[2][4];          // per-wave partial sums of the two KL forms
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int arow = min(m0 + (lane & 15), B - 1), bcol = min(n0 + (lane & 15), Z - 1);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    skinny_accum_kk(acc0, acc1, lh, (long)arow * K, Wlv, (long)bcol * K, K, wave, lane);
+    skinny_store_partial(red, acc0, acc1, wave, lane);
+    __syncthreads();
+    const int row = tid >> 4, col = tid & 15;
+    const int gr = m0 + row, gc = n0 + col;
+    float klmi = 0.f, klfb = 0.f, mc_v = 0.f, var_v = 0.f;
+    if (gr < B && gc < Z) {
+        const long i = (long)gr * Z + gc;
+        const float lvr = skinny_reduced(red, row, col) + blv[gc];
+        lv_raw[i] = lvr;
+        const float m = tanhf(mu_raw[i] / 2.0f) * 2.0f;
+        const float lv = tanhf(lvr / 2.0f) * 1.0f - 1.0f;
+        mu[i] = m;
+        logvar[i] = lv;
+        z[i] = m + eps[i] * expf(0.5f * lv);
+        const float mc = clipf(m, -3.0f, 3.0f), lc = clipf(lv, -6.0f, 3.0f);
+        const float var = expf(lc);
+        const float k = -0.5f * (1.0f + lc - mc * mc - var);
+        mc_v = mc; var_v = var;
+        klmi = k;
+        float kf = fmaxf(k, 0.0f);
+        if (fb_min > 0.0f) kf = fmaxf(kf, fb_min);
+        klfb = kf;
+    }
+    cs[0][row][col] = mc_v;
+    cs[1][row][col] = var_v;
+    klmi = wave_sum(klmi);
+    klfb = wave_sum(klfb);
+    if (lane == 0) { rs[0][wave] = klmi; rs[1][wave] = klfb; }
+    __syncthreads();
+    if (tid < 32) {                      // column sums of the tile: 16 columns x {mu, var}
+        const int q = tid >> 4, c = tid & 15;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += cs[q][r][c];
+        if (n0 + c < Z) atomicAdd(stats + q * Z + n0 + c, a);
+    } else if (tid == 32) {
+        atomicAdd(stats + 2 * Z, (rs[0][0] + rs[0][1]) + (rs[0][2] + rs[0][3]));
+        atomicAdd(stats + 2 * Z + 1, (rs[1][0] + rs[1][1]) + (rs[1][2] + rs[1][3]));
+        if (blockIdx.x == 0) atomicAdd(stats + 2 * Z + 2, (float)min(16, B - m0));
     }
 }
 
@@ -201,22 +261,44 @@ extern "C" int arcvae_enc_heads_forward(const float* hT, const float* cond, cons
                                         const float* Wlv, const float* blv, const float* eps, float* comb,
                                         float* lh, float* mu_raw, float* lv_raw, float* mu, float* logvar,
                                         float* z, float* stats, int B, int H, int Z, int C, float free_bits,
-                                        hipStream_t stream) {
-    if (!hT || !cond || !Wc || !bc || !Wmu || !bmu || !Wlh || !blh || !Wlv || !blv || !eps || !comb || !lh ||
-        !mu_raw || !lv_raw || !mu || !logvar || !z || !stats)
+                                        int comb_ready, hipStream_t stream) {
+    if (!Wmu || !bmu || !Wlh || !blh || !Wlv || !blv || !eps || !comb || !lh || !mu_raw || !lv_raw || !mu || !logvar ||
+        !z || !stats)
         return ARCVAE_ERR_ARG;
+    if (!comb_ready && (!hT || !cond || !Wc || !bc)) return ARCVAE_ERR_ARG;
     if (B <= 0 || H <= 0 || Z <= 0 || C < 0) return ARCVAE_ERR_ARG;
     const int H2 = 2 * H;
     if (2 * Z + 4 > B * H2) return ARCVAE_ERR_ARG;
-    hipLaunchKernelGGL(build_comb_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, hT, cond, Wc, bc, comb,
-                       stats, 2 * Z + 4, B, H, C);
-    int rc = arcvae_gemm_f32(0, 1, B, Z, H2, comb, H2, Wmu, H2, mu_raw, Z, bmu, 0, stream);
+    // comb_ready: comb [B,2H] and the zeroed stats were written ahead of this call (arcvae_enc_prologue wrote the
+    // condition half and cleared stats, the persistent forward sweep stored h_{T-1} of the top layer into the other half)
+    if (!comb_ready)
+        hipLaunchKernelGGL(build_comb_kernel, dim3(ceil_div(B * H2, 256)), dim3(256), 0, stream, hT, cond, Wc, bc, comb,
+                           stats, 2 * Z + 4, B, H, C);
+    const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
+    int rc;
+    const bool fast = B <= 256 && (H2 % 64) == 0 && (reinterpret_cast<uintptr_t>(comb) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(Wmu) & 15) == 0 && (reinterpret_cast<uintptr_t>(Wlh) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(Wlv) & 15) == 0 && (reinterpret_cast<uintptr_t>(lh) & 15) == 0;
+    if (fast) {
+        // [mu_raw | lh = tanh(.)] in one launch, then lv_raw with latent_apply as its epilogue: 2 launches instead of 4
+        const int M[2] = {B, B}, N[2] = {Z, H2}, K[2] = {H2, H2}, lda[2] = {H2, H2}, ldb[2] = {H2, H2}, ldc[2] = {Z, H2};
+        const float* A[2] = {comb, comb};
+        const float* Bm[2] = {Wmu, Wlh};
+        float* Cm[2] = {mu_raw, lh};
+        const float* bias[2] = {bmu, blh};
+        const int fl[2] = {0, ARCVAE_GEMM_TANH};
+        rc = arcvae_gemm_skinny_pair(1, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias, fl, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(heads_lv_apply_kernel, dim3(ceil_div(Z, 16), ceil_div(B, 16)), dim3(256), 0, stream, lh, Wlv, blv,
+                           mu_raw, eps, lv_raw, mu, logvar, z, stats, B, Z, H2, fb_min);
+        return arcvae_launch_status();
+    }
+    rc = arcvae_gemm_f32(0, 1, B, Z, H2, comb, H2, Wmu, H2, mu_raw, Z, bmu, 0, stream);
     if (rc) return rc;
     rc = arcvae_gemm_f32(0, 1, B, H2, H2, comb, H2, Wlh, H2, lh, H2, blh, ARCVAE_GEMM_TANH, stream);
     if (rc) return rc;
     rc = arcvae_gemm_f32(0, 1, B, Z, H2, lh, H2, Wlv, H2, lv_raw, Z, blv, 0, stream);
     if (rc) return rc;
-    const float fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
     hipLaunchKernelGGL(latent_apply_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, mu_raw, lv_raw, eps, mu,
                        logvar, z, stats, B, Z, fb_min);
     return arcvae_launch_status();
@@ -333,10 +415,22 @@ extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, co
     const int ACC = ARCVAE_GEMM_ACCUMULATE;
     int rc;
     if (phase == 0 || phase == 1) {
+        const bool pair = B <= 256 && (Z % 64) == 0 && (reinterpret_cast<uintptr_t>(dmu_raw) & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(dlv_raw) & 15) == 0;
+        if (pair) {   // dcomb = dmu_raw . Wmu and dlh = (dlv_raw . Wlv) * (1 - lh^2) in one launch
+            const int M[2] = {B, B}, N[2] = {H2, H2}, K[2] = {Z, Z}, lda[2] = {Z, Z}, ldb[2] = {H2, H2}, ldc[2] = {H2, H2};
+            const float* A[2] = {dmu_raw, dlv_raw};
+            const float* Bm[2] = {Wmu, Wlv};
+            float* Cm[2] = {dcomb, dlh};
+            const float* bias[2] = {nullptr, lh};
+            const int fl[2] = {0, ARCVAE_GEMM_DTANH};
+            if ((rc = arcvae_gemm_skinny_pair(0, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias, fl, stream))) return rc;
+        } else {
         if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dmu_raw, Z, Wmu, H2, dcomb, H2, nullptr, 0, stream))) return rc;
         // dlh = (dlv_raw . Wlv) * (1 - lh^2): tanh backward fused into the GEMM epilogue
         if ((rc = arcvae_gemm_f32(0, 0, B, H2, Z, dlv_raw, Z, Wlv, H2, dlh, H2, lh, ARCVAE_GEMM_DTANH, stream)))
             return rc;
+        }
         if ((rc = arcvae_gemm_f32(0, 0, B, H2, H2, dlh, H2, Wlh, H2, dcomb, H2, nullptr, ACC, stream))) return rc;
     }
     if (phase == 0 || phase == 2) {

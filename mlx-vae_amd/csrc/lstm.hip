@@ -731,6 +731,7 @@ struct PersistArgs {
     float* hseq;
     float* cseq;
     float* gseq;
+    float* comb;                             // or null: [B,2H], its first H columns receive h_{T-1} of the top layer (heads' input)
     unsigned* sync;                          // PS_WORDS words, zeroed before the launch
     unsigned* start_signal;                  // or null: += 1 once, when the sweep starts
     unsigned long long* trace;               // or null: {start, end} per tick of block (xcc 0, role 0)
@@ -1053,7 +1054,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                 const float c = te > 0 ? gf * cst[i] + gi * gg : gi * gg;   // MLX: cell=None at t == 0 -> c = i*g
                 cst[i] = c;
                 const long hb = (long)b * H + unit;
-                a.hseq[el * lH + (long)te * sH + hb] = go * chain_tanh(c);
+                const float hval = go * chain_tanh(c);
+                a.hseq[el * lH + (long)te * sH + hb] = hval;
+                if (a.comb && el == LL - 1 && te == T - 1) a.comb[(long)b * 2 * H + unit] = hval;
                 float* gp = a.gseq + el * lG + (long)te * sG + (long)b * G + unit;
                 gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
                 a.cseq[el * lH + (long)te * sH + hb] = c;
@@ -1897,9 +1900,9 @@ extern "C" int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L) { retur
 // sync_ws[500] != 0 means a block gave up waiting (results invalid: fall back to arcvae_enc_lstm_forward).
 extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                                   const float* const* Wh, const float* const* bias, float* hseq,
-                                                  float* cseq, float* gseq, float* wT_bwd, unsigned* sync_ws,
-                                                  unsigned* start_signal, int B, int T, int V, int H, int L, int flags,
-                                                  unsigned long long* trace, hipStream_t stream) {
+                                                  float* cseq, float* gseq, float* wT_bwd, float* comb,
+                                                  unsigned* sync_ws, unsigned* start_signal, int B, int T, int V, int H,
+                                                  int L, int flags, unsigned long long* trace, hipStream_t stream) {
     if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq || !sync_ws) return ARCVAE_ERR_ARG;
     if (V <= 0 || !persist_shape_ok(B, T, H, L)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
@@ -1914,7 +1917,7 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
         if (rc != ARCVAE_OK) return rc;
     }
     PersistArgs a;
-    a.x_tb = x_tb; a.table0 = table0; a.hseq = hseq; a.cseq = cseq; a.gseq = gseq;
+    a.x_tb = x_tb; a.table0 = table0; a.hseq = hseq; a.cseq = cseq; a.gseq = gseq; a.comb = comb;
     for (int i = 0; i < 7; ++i) a.W[i] = Wh[0];
     for (int l = 0; l < L; ++l) { a.W[l] = Wh[l]; if (l > 0) a.W[L + l - 1] = Wx[l]; }
     for (int l = 0; l < ARCVAE_MAX_LAYERS; ++l) a.bias[l] = (l > 0 && l < L) ? bias[l] : nullptr;

@@ -387,8 +387,20 @@ extern "C" int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw,
 // took ~70 us on uncoalesced weight rows) -----------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __restrict__ x_bt, int32_t* x_tb, int B, int T,
-                                                           float4* zero, long nz4, unsigned* sync, int nsync) {
+                                                           float4* zero, long nz4, unsigned* sync, int nsync,
+                                                           const float* __restrict__ cond, const float* __restrict__ Wc,
+                                                           const float* __restrict__ bc, float* comb, float* stats,
+                                                           int nstats, int H, int C) {
     const long gt = (long)blockIdx.x * 256 + threadIdx.x, gs = (long)gridDim.x * 256;
+    if (comb) {   // comb[b, H + u] = bc[u] + sum_c cond[b,c] * Wc[u,c]   (models/encoder.py:109-112); stats = 0
+        for (long i = gt; i < (long)B * H; i += gs) {
+            const int b = (int)(i / H), u = (int)(i - (long)b * H);
+            float a = 0.f;
+            for (int c = 0; c < C; ++c) a += cond[b * C + c] * Wc[u * C + c];
+            comb[(long)b * 2 * H + H + u] = a + bc[u];
+        }
+        for (long i = gt; i < nstats; i += gs) stats[i] = 0.f;
+    }
     for (long i = gt; i < (long)B * T; i += gs) {
         const int t = (int)(i / B), bb = (int)(i % B);
         x_tb[i] = x_bt[(long)bb * T + t];
@@ -402,13 +414,19 @@ __global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __rest
 // x_bt [B,T] -> x_tb [T,B];  zero_f32 (optional, 16-byte aligned, n_zero % 4 == 0) = 0;  sync_ws[0 .. n_sync) = 0
 // (optional).  Replaces arcvae_transpose_tokens + the gradient memset + the sweep's re-arm in front of
 // arcvae_enc_lstm_forward_persistent(flags & 1).
+// cond .. comb (optional, all or none): also the condition half of the heads' input, comb[:, H:2H] = condition_fc(cond)
+// (models/encoder.py:109-112), and stats[0 .. n_stats) = 0 -- with the sweep storing h_{T-1} into comb[:, :H] the heads
+// need no build_comb launch (arcvae_enc_heads_forward(comb_ready = 1)).
 extern "C" int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, unsigned* sync_ws,
-                                   int n_sync, int B, int T, hipStream_t stream) {
+                                   int n_sync, const float* cond, const float* Wc, const float* bc, float* comb,
+                                   float* stats, int n_stats, int B, int T, int H, int C, hipStream_t stream) {
     if (!x_bt || !x_tb || B <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    if (comb && (!cond || !Wc || !bc || !stats || n_stats <= 0 || H <= 0 || C < 0)) return ARCVAE_ERR_ARG;
     if (zero_f32 && ((n_zero % 4) != 0 || (reinterpret_cast<uintptr_t>(zero_f32) & 15) != 0)) return ARCVAE_ERR_ARG;
     if (n_sync < 0 || (n_sync > 0 && !sync_ws)) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(enc_prologue_kernel, dim3(256), dim3(256), 0, stream, x_bt, x_tb, B, T,
-                       reinterpret_cast<float4*>(zero_f32), zero_f32 ? n_zero / 4 : 0L, sync_ws, n_sync);
+                       reinterpret_cast<float4*>(zero_f32), zero_f32 ? n_zero / 4 : 0L, sync_ws, n_sync, cond, Wc, bc, comb,
+                       stats, n_stats, H, C);
     return arcvae_launch_status();
 }
 

@@ -17,6 +17,11 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
                                const float* const* B, int ldb, float* const* C, int ldc, bool allow_split,
                                hipStream_t stream);
 
+// internal (C++ linkage): two skinny products in one launch, see gemm.hip
+int arcvae_gemm_skinny_pair(int transB, const int* M, const int* N, const int* K, const float* const* A, const int* lda,
+                            const float* const* B, const int* ldb, float* const* C, const int* ldc,
+                            const float* const* bias, const int* flags, hipStream_t stream);
+
 extern "C" {
 int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
                     const float* B, int ldb, float* C, int ldc, const float* bias, int flags,
