@@ -105,10 +105,11 @@ int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0,
  * zero_f32[0..n_zero) = 0 (optional: the encoder's gradient buffer), sync_ws[0..n_sync) = 0 (optional: the sweep's
  * re-arm). */
 /* cond .. stats (optional, all or none): also comb[:, H:2H] = condition_fc(cond) (models/encoder.py:109-112) and
- * stats[0..n_stats) = 0, for arcvae_enc_heads_forward(comb_ready = 1). */
+ * stats[0..n_stats) = 0, for arcvae_enc_heads_forward(comb_ready = 1).  onehot_ws (optional, [T*B, roundup(V,4)]): the
+ * one-hot token rows of arcvae_enc_lstm_wgrad (called with parts bit 5 then). */
 int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, unsigned* sync_ws, int n_sync,
                         const float* cond, const float* Wc, const float* bc, float* comb, float* stats, int n_stats,
-                        int B, int T, int H, int C, arcvae_stream_t stream);
+                        float* onehot_ws, int V, int B, int T, int H, int C, arcvae_stream_t stream);
 int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, const float* dh_top, int ld_dh_top,
                                         float* dG, float* dcs, float* dxs, const float* wT, unsigned* sync_ws,
@@ -142,7 +143,9 @@ int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* W
  * embedding / layer-0 gradients.  dtable_ws [V,4H]; onehot_ws [T*B, roundup(V,4)] (one-hot token rows, written
  * when `first`: the token segment-sum runs as OneHot^T . dG_0 on the matrix cores).  `parts` selects disjoint pieces
  * that may run on different streams: bit 0 = per-layer GEMMs and bias sums (= bits 2 | 3), bit 1 = token-table path,
- * bit 2 = dWx_l (l >= 1) and bias sums only, bit 3 = dWh_l only. */
+ * bit 2 = dWx_l (l >= 1) and bias sums only, bit 3 = dWh_l only; bit 4 = exact-f32 tile GEMMs instead of the split-bf16
+ * kernel; bit 5 = onehot_ws was written by arcvae_enc_prologue.  The token-table path is linear in dtable_ws, so a
+ * time range may be given its own workspace and both `first` and `last` (zero, accumulate, fold) on any stream. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
                           const float* dG, float* dtable_ws, float* onehot_ws, float* dEmb, float* const* dWx,
                           float* const* dWh, float* const* dbias, int B, int T, int V, int E, int H, int L,

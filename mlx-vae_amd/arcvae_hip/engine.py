@@ -119,6 +119,7 @@ class Workspace:
             self.dxs = torch.empty(L, RS, B, H, **f32)
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
             self.dtable0 = torch.empty(V, G, **f32)
+            self.dtable1 = torch.empty(V, G, **f32)           # the last chunk's token table, folded by the main stream itself
             self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)
             if H == 256 and L <= 2 and B <= 256:  # partial sums in flight of the reduce-scatter BPTT sweep (12.6 MB per
                 rg = 1 if B <= 64 else (2 if B <= 128 else 4)   # group of 8 rows per XCD)
@@ -180,7 +181,8 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         grad = enc.grad if zero_grad else None
         call("arcvae_enc_prologue", ptr(ws.x), ptr(ws.x_tb), ptr(grad), C.c_long(grad.numel() if grad is not None else 0),
              ptr(ws.psync), 272, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
-             ptr(ws.comb), ptr(ws.stats), 2 * d.Z + 4, B, T, d.H, d.C, s)
+             ptr(ws.comb), ptr(ws.stats), 2 * d.Z + 4, ptr(ws.onehot) if (zero_grad and hasattr(ws, "onehot")) else C.c_void_p(0),
+             d.V, B, T, d.H, d.C, s)
         comb_ready = 1
         call("arcvae_gemm_f32", 0, 1, d.V, G, d.E, ptr(enc.p("embedding.weight")), d.E,
              ptr(enc.p("lstm_layer_0.Wx")), d.E, ptr(ws.table0), G, ptr(enc.p("lstm_layer_0.bias")), 0, s)
@@ -440,7 +442,10 @@ class EncoderBackwardPlan:
              0,  # retile = 0: the forward of this step already wrote the BPTT weight layouts
              start_signal if start_signal is not None else C.c_void_p(0), ptr(ws.trace_bwd), stream_ptr())
 
-    def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3) -> None:
+    def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3, table=None) -> None:
+        """Weight gradients of the time range.  `table`: token-table workspace of this call (default ws.dtable0); the
+        table path is linear, so a range may own a workspace and be zeroed, accumulated and folded by itself
+        (first = last = True)."""
         enc, ws, d = self.enc, self.ws, self.d
         if os.environ.get("ARCVAE_DEBUG_SKIP_WGRAD", "0") == "1":   # timing experiments only (gradients are WRONG)
             return
@@ -459,7 +464,8 @@ class EncoderBackwardPlan:
             # tile GEMM is the faster one (bs 256: 3.254 vs 3.363 ms).
             parts |= 16
         call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
-             ptr(ws.hseq), ptr(ws.dG), ptr(ws.dtable0), ptr(ws.onehot), ptr(enc.g("embedding.weight")), self._dwx[0],
+             ptr(ws.hseq), ptr(ws.dG), ptr(table if table is not None else ws.dtable0), ptr(ws.onehot),
+             ptr(enc.g("embedding.weight")), self._dwx[0],
              self._dwh[0],
              self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), parts, stream_ptr())
 
@@ -519,6 +525,12 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
         main.wait_stream(aux2)
 
 
+def _tables_on_main(plan, ws) -> bool:
+    """Every BPTT chunk folds its own token table and main forms the last chunk's (see _encoder_backward_gated)."""
+    return (ws is not None and hasattr(ws, "dtable1") and os.environ.get("ARCVAE_TABLE_ON_MAIN", "1") != "0"
+            and persistent_forward_ok(ws, plan.d))
+
+
 def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2, run, prologue, after_first,
                             g: Gates) -> None:
     """encoder_backward with device-side gates instead of event waits (class Gates).  Main's signals of a step:
@@ -544,6 +556,12 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     # (1.084-1.088 vs 1.073 ms); with the two late chunks of the persistent sweep it is what makes them pay
     # (ARCVAE_WX_ON_SIDE=0/1 overrides).
     wx_on_side = table_on_side and os.environ.get("ARCVAE_WX_ON_SIDE", "1" if plan.persistent else "0") != "0"
+    # Round 2: the token-table path is linear, so every chunk folds its OWN table (zero, one-hot GEMM, fold: first = last
+    # = True) -- and the LAST chunk's, the only one in the exposed tail, is formed by main itself right behind the sweep
+    # (main is idle there and needs no gate for its own sweep), in parallel with the last dWx on side and dWh on aux:
+    # side's tail was a chain of four kernels (~100 us).  Needs the one-hot rows from arcvae_enc_prologue (persistent
+    # forward path).  ARCVAE_TABLE_ON_MAIN=0: round 1's accumulate-on-side form.
+    own_tables = table_on_side and _tables_on_main(plan, ws)
 
     def main_seg():
         # the whole critical chain of the backward as ONE captured segment: the "chunk c done" signal is raised by
@@ -555,6 +573,9 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
         for c, (s0, s1, _t_lo, _t_hi, _first, _last) in enumerate(plan.chunks):
             plan.sweep(s0, s1, g.word(g.P) if c > 0 else None, c)
         g.signal(g.P, g.STRIDE - nc)
+        if own_tables:
+            _s0, _s1, t_lo_l, t_hi_l, _f, _l = plan.chunks[-1]
+            plan.wgrad(t_lo_l, t_hi_l, True, True, 2 | 32, table=getattr(ws, "dtable1", None))
 
     run("main", main_seg, main)
     if after_first:
@@ -577,7 +598,10 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             else:
                 g.wait(g.Q, g.NS, 1, 1)
                 g.wait(g.P, g.NS, g.STRIDE, g.STRIDE, advance=True)
-            plan.wgrad(t_lo, t_hi, first, last, 6 if wx_on_side else 2)
+            if own_tables:   # this chunk's own table (not the last chunk's: main forms that one)
+                plan.wgrad(t_lo, t_hi, True, True, ((4 if wx_on_side else 0) | (0 if last else 2)) | 32)
+            else:
+                plan.wgrad(t_lo, t_hi, first, last, 6 if wx_on_side else 2)
             if last:
                 g.signal(g.R, 1)
 

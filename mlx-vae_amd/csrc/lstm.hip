@@ -2199,6 +2199,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   when `last` != 0 (all ranges done): dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;  dbias_0 += colsum(dTable0)
 //   parts: bit 0 = the per-layer GEMMs (= bits 2 | 3), bit 1 = the layer-0 token-table path, bit 2 = only the dWx_l
 //   GEMMs (l >= 1) and the bias column sums, bit 3 = only the dWh_l GEMMs (disjoint outputs: up to three streams);
+//   bit 5 = onehot_ws already holds the one-hot rows (arcvae_enc_prologue);
 //   bit 4 = exact-f32 MFMA tile GEMMs instead of the split-bf16 kernel (45 instead of 208 registers per lane: what
 //   fits on a SIMD beside a persistent sweep wave of more than 296 registers, i.e. the 2 / 4 row-group sweeps)
 //   onehot_ws [T*B, roundup(V,4)] workspace: one-hot token rows, written when `first` != 0 (token-table part)
@@ -2220,6 +2221,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     if (do_table && first) {
         if (arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
         const long n = (long)TB * Vp;
+        if (!(parts & 32))   // bit 5: the one-hot rows were written by arcvae_enc_prologue
         hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, stream, x_tb,
                            TB, V, Vp, onehot_ws);
     }

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void table_finalize_kernel(const float* __rest
                 for (int i = 0; i < 8; ++i) acc[i] = fmaf(tt[v * 16 + half * 8 + i], x, acc[i]);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dWx0[(long)(g0 + half * 8 + i) * ldw + e] += acc[i];
+            for (int i = 0; i < 8; ++i) atomicAdd(dWx0 + (long)(g0 + half * 8 + i) * ldw + e, acc[i]);   // atomic: two
+            // chunks' tables may be folded at the same time on different streams (engine: side and main)
         }
         return;
     }
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void table_finalize_kernel(const float* __rest
     if (g < G) {
         float a = 0.f;
         for (int v = 0; v < V; ++v) a += dT[(long)v * G + g];
-        db0[g] += a;
+        atomicAdd(db0 + g, a);
     }
 }
 
@@ -390,8 +391,17 @@ __global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __rest
                                                            float4* zero, long nz4, unsigned* sync, int nsync,
                                                            const float* __restrict__ cond, const float* __restrict__ Wc,
                                                            const float* __restrict__ bc, float* comb, float* stats,
-                                                           int nstats, int H, int C) {
+                                                           int nstats, int H, int C, float* onehot, int V, int Vp) {
     const long gt = (long)blockIdx.x * 256 + threadIdx.x, gs = (long)gridDim.x * 256;
+    if (onehot) {   // one-hot token rows [T*B, Vp] (row r = t*B + b) for the token-table gradient GEMMs of the BPTT chunks
+        const long n = (long)B * T * Vp;
+        for (long i = gt; i < n; i += gs) {
+            const int r = (int)(i / Vp), v = (int)(i - (long)r * Vp);
+            const int t = r / B, bb = r - t * B;
+            const int tk = min(max(x_bt[(long)bb * T + t], 0), V - 1);
+            onehot[i] = (v == tk) ? 1.0f : 0.0f;
+        }
+    }
     if (comb) {   // comb[b, H + u] = bc[u] + sum_c cond[b,c] * Wc[u,c]   (models/encoder.py:109-112); stats = 0
         for (long i = gt; i < (long)B * H; i += gs) {
             const int b = (int)(i / H), u = (int)(i - (long)b * H);
@@ -416,17 +426,20 @@ __global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __rest
 // arcvae_enc_lstm_forward_persistent(flags & 1).
 // cond .. comb (optional, all or none): also the condition half of the heads' input, comb[:, H:2H] = condition_fc(cond)
 // (models/encoder.py:109-112), and stats[0 .. n_stats) = 0 -- with the sweep storing h_{T-1} into comb[:, :H] the heads
-// need no build_comb launch (arcvae_enc_heads_forward(comb_ready = 1)).
+// need no build_comb launch (arcvae_enc_heads_forward(comb_ready = 1)).  onehot_ws (optional, [T*B, roundup(V,4)]): the
+// one-hot token rows of arcvae_enc_lstm_wgrad (then called with parts bit 5).
 extern "C" int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, unsigned* sync_ws,
                                    int n_sync, const float* cond, const float* Wc, const float* bc, float* comb,
-                                   float* stats, int n_stats, int B, int T, int H, int C, hipStream_t stream) {
+                                   float* stats, int n_stats, float* onehot_ws, int V, int B, int T, int H, int C,
+                                   hipStream_t stream) {
     if (!x_bt || !x_tb || B <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    if (onehot_ws && V <= 0) return ARCVAE_ERR_ARG;
     if (comb && (!cond || !Wc || !bc || !stats || n_stats <= 0 || H <= 0 || C < 0)) return ARCVAE_ERR_ARG;
     if (zero_f32 && ((n_zero % 4) != 0 || (reinterpret_cast<uintptr_t>(zero_f32) & 15) != 0)) return ARCVAE_ERR_ARG;
     if (n_sync < 0 || (n_sync > 0 && !sync_ws)) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(enc_prologue_kernel, dim3(256), dim3(256), 0, stream, x_bt, x_tb, B, T,
                        reinterpret_cast<float4*>(zero_f32), zero_f32 ? n_zero / 4 : 0L, sync_ws, n_sync, cond, Wc, bc, comb,
-                       stats, n_stats, H, C);
+                       stats, n_stats, H, C, onehot_ws, V, (V + 3) & ~3);
     return arcvae_launch_status();
 }
 

@@ -59,9 +59,10 @@ class _Plan:
             self.g.note("signal", E.Gates.P, 1)
         self.g.note("sweep_done", c)
 
-    def wgrad(self, t_lo, t_hi, first, last, parts=3):
-        c = [i for i, ch in enumerate(self.chunks) if ch[2] == t_lo and ch[3] == t_hi and ch[5] == last][0]
-        self.g.note("wgrad", c, parts)
+    def wgrad(self, t_lo, t_hi, first, last, parts=3, table=None):
+        c = [i for i, ch in enumerate(self.chunks) if ch[2] == t_lo and ch[3] == t_hi][0]
+        if parts & 15:
+            self.g.note("wgrad", c, parts & 15)     # bits 4, 5 choose kernels / workspaces, not pieces
 
 
 def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
@@ -148,7 +149,10 @@ def _replay(ops, streams, steps):
 @pytest.mark.parametrize("T,L,fractions", [(128, 2, (0.3, 0.6, 0.85, 1.0)), (128, 2, (0.63, 1.0)), (12, 2, (0.63, 1.0)),
                                            (40, 4, (0.1, 0.2, 0.3, 0.5, 0.7, 0.9, 1.0)), (9, 1, (0.5, 1.0)), (5, 3, (0.3, 0.6, 0.85, 1.0))])
 @pytest.mark.parametrize("dp", [False, True])
-def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persistent, env, dp, monkeypatch):
+@pytest.mark.parametrize("tables_on_main", [False, True])
+def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persistent, env, dp, tables_on_main, monkeypatch):
+    # tables_on_main: every chunk folds its own token table, main forms the last chunk's behind its own sweep (round 2)
+    monkeypatch.setattr(E, "_tables_on_main", lambda plan, ws: tables_on_main)
     ops, streams, nc = _record_step(T, L, fractions, persistent, env, monkeypatch, dp)
     assert nc >= 2
     steps = 5
