@@ -527,8 +527,10 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
 
 def _tables_on_main(plan, ws) -> bool:
     """Every BPTT chunk folds its own token table and main forms the last chunk's (see _encoder_backward_gated)."""
+    # (beside the persistent reduce-scatter sweep only: with the per-step launches of larger batches the accumulate-on-side
+    # form is the faster one -- bs 256: 3.321 vs 3.354 ms)
     return (ws is not None and hasattr(ws, "dtable1") and os.environ.get("ARCVAE_TABLE_ON_MAIN", "1") != "0"
-            and persistent_forward_ok(ws, plan.d))
+            and bool(getattr(plan, "persistent", False)) and persistent_forward_ok(ws, plan.d))
 
 
 def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2, run, prologue, after_first,
