@@ -40,7 +40,8 @@ extern "C" {
 #define ARCVAE_GEMM_NO_SKINNY 8
 #define ARCVAE_GEMM_TILE64 16   /* force 64x64 tiles (tuning / tests) */
 #define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
-#define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */  /* force the tile kernel                      */
+#define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */
+#define ARCVAE_GEMM_TILE_WIDE 128 /* split-bf16 TN path: 128-row tile (no persistent sweep resident beside it) */
 
 typedef void* arcvae_stream_t; /* hipStream_t */
 
@@ -144,7 +145,8 @@ int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* W
  * when `first`: the token segment-sum runs as OneHot^T . dG_0 on the matrix cores).  `parts` selects disjoint pieces
  * that may run on different streams: bit 0 = per-layer GEMMs and bias sums (= bits 2 | 3), bit 1 = token-table path,
  * bit 2 = dWx_l (l >= 1) and bias sums only, bit 3 = dWh_l only; bit 4 = exact-f32 tile GEMMs instead of the split-bf16
- * kernel; bit 5 = onehot_ws was written by arcvae_enc_prologue.  The token-table path is linear in dtable_ws, so a
+ * kernel; bit 5 = onehot_ws was written by arcvae_enc_prologue; bit 6 = the split-bf16 kernel's 128-row tile (the range
+ * runs behind the sweep, no sweep block is resident).  The token-table path is linear in dtable_ws, so a
  * time range may be given its own workspace and both `first` and `last` (zero, accumulate, fold) on any stream. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
                           const float* dG, float* dtable_ws, float* onehot_ws, float* dEmb, float* const* dWx,

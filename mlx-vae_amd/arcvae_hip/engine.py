@@ -463,6 +463,10 @@ class EncoderBackwardPlan:
             # the 2-group sweep (343 registers) it cannot be resident, and beside the per-step launches the exact-f32
             # tile GEMM is the faster one (bs 256: 3.254 vs 3.363 ms).
             parts |= 16
+        elif last and os.environ.get("ARCVAE_WIDE_TAIL", "0") == "1":
+            # opt-in: the last chunk's GEMMs run behind the sweep, so the 128-row split tile could be resident -- measured
+            # slower (1.072 vs 1.028 ms: three concurrent launches of one-block-per-CU kernels serialise in the tail)
+            parts |= 64
         call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
              ptr(ws.hseq), ptr(ws.dG), ptr(table if table is not None else ws.dtable0), ptr(ws.onehot),
              ptr(enc.g("embedding.weight")), self._dwx[0],

@@ -429,7 +429,7 @@ inline bool split_tn_ok(int M, int N, const float* A, int lda, const float* B, i
     return split_tn_enabled() && (M % 4) == 0 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && M >= 32 && N >= 16;
 }
 // n same-layout problems in one launch; K slices of `kslice` (multiple of 16) walk blockIdx.z
-int launch_split_tn_group(int n, const SplitTN* probs, hipStream_t stream) {
+int launch_split_tn_group(int n, const SplitTN* probs, bool wide, hipStream_t stream) {
     SplitTNGroup g;
     g.n = n;
     int Mmax = 0, Nmax = 0, ztot = 0;
@@ -438,8 +438,10 @@ int launch_split_tn_group(int n, const SplitTN* probs, hipStream_t stream) {
         g.p[i] = probs[i];
         Mmax = max(Mmax, probs[i].M); Nmax = max(Nmax, probs[i].N);
     }
-    // ARCVAE_SPLIT_TILE: 2 (default) = 64 x 64 tiles (fits beside a persistent sweep), 4 = 128 x 64
-    static const int mi = arcvae_env_int("ARCVAE_SPLIT_TILE", 2) == 4 ? 4 : 2;
+    // ARCVAE_SPLIT_TILE: 2 (default) = 64 x 64 tiles (fits beside a persistent sweep), 4 = 128 x 64 everywhere;
+    // `wide`: the caller knows no sweep is resident (the last chunk's GEMMs run behind the sweep): 128 x 64
+    static const int mi_env = arcvae_env_int("ARCVAE_SPLIT_TILE", 2) == 4 ? 4 : 2;
+    const int mi = wide ? 4 : mi_env;
     const int tiles = ceil_div(Mmax, 32 * mi) * ceil_div(Nmax, 64);
     for (int i = 0; i < n; ++i) {
         SplitTN& p = g.p[i];
@@ -542,7 +544,7 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
         !(flags & (ARCVAE_GEMM_TILE64 | ARCVAE_GEMM_TILE128)) && split_tn_ok(M, N, A, lda, B, ldb)) {
         SplitTN q;
         q.A = A; q.B = B; q.C = C; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.kchunk = 0;
-        return launch_split_tn_group(1, &q, stream);
+        return launch_split_tn_group(1, &q, (flags & ARCVAE_GEMM_TILE_WIDE) != 0, stream);
     }
     // Skinny path: minibatch-sized M on the critical path.
     if (!(flags & ARCVAE_GEMM_NO_SKINNY) && ak && M <= 256 && (K % 64) == 0 && (lda % 4) == 0 &&
@@ -618,10 +620,10 @@ int arcvae_gemm_skinny_pair(int transB, const int* M, const int* N, const int* K
 // atomics (split-K inside each problem).  Internal (ops.h); falls back to n single launches when the operands do
 // not allow the 16-byte path.
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
-                               const float* const* B, int ldb, float* const* C, int ldc, bool allow_split,
+                               const float* const* B, int ldb, float* const* C, int ldc, int allow_split,
                                hipStream_t stream) {
     if (n <= 0 || n > ARCVAE_GEMM_GROUP_MAX || M <= 0 || N <= 0) return ARCVAE_ERR_ARG;
-    if (allow_split) {
+    if (allow_split) {   // 1 = split-bf16, 2 = split-bf16 with the 128-row tile (no sweep resident)
         bool ok = true;
         for (int i = 0; i < n; ++i) ok = ok && K[i] > 0 && split_tn_ok(M, N, A[i], lda, B[i], ldb);
         if (ok) {
@@ -630,7 +632,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
                 q[i].A = A[i]; q[i].B = B[i]; q[i].C = C[i]; q[i].M = M; q[i].N = N; q[i].K = K[i];
                 q[i].lda = lda; q[i].ldb = ldb; q[i].ldc = ldc; q[i].kchunk = 0;
             }
-            return launch_split_tn_group(n, q, stream);
+            return launch_split_tn_group(n, q, allow_split == 2, stream);
         }
     }
     bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0;

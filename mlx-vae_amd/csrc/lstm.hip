@@ -2199,7 +2199,8 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   when `last` != 0 (all ranges done): dEmb += dTable0 . Wx_0;  dWx_0 += dTable0^T . Emb;  dbias_0 += colsum(dTable0)
 //   parts: bit 0 = the per-layer GEMMs (= bits 2 | 3), bit 1 = the layer-0 token-table path, bit 2 = only the dWx_l
 //   GEMMs (l >= 1) and the bias column sums, bit 3 = only the dWh_l GEMMs (disjoint outputs: up to three streams);
-//   bit 5 = onehot_ws already holds the one-hot rows (arcvae_enc_prologue);
+//   bit 5 = onehot_ws already holds the one-hot rows (arcvae_enc_prologue);  bit 6 = 128-row split-bf16 tile (this range
+//   runs behind the sweep: no sweep block is resident, the 322-register tile fits);
 //   bit 4 = exact-f32 MFMA tile GEMMs instead of the split-bf16 kernel (45 instead of 208 registers per lane: what
 //   fits on a SIMD beside a persistent sweep wave of more than 296 registers, i.e. the 2 / 4 row-group sweeps)
 //   onehot_ws [T*B, roundup(V,4)] workspace: one-hot token rows, written when `first` != 0 (token-table part)
@@ -2215,7 +2216,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     const long lH = (long)TB * H, lG = (long)TB * G;
     int rc;
     const bool do_wx = (parts & (1 | 4)) != 0, do_wh = (parts & (1 | 8)) != 0, do_table = (parts & 2) != 0;
-    const bool exact_f32 = (parts & 16) != 0;
+    const bool exact_f32 = (parts & 16) != 0, wide = (parts & 64) != 0;
     const bool do_layers = do_wx || do_wh;
     const int Vp = (V + 3) & ~3;
     if (do_table && first) {
@@ -2247,7 +2248,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
             }
             for (int i = 0; i < n; i += 8) {
                 rc = arcvae_gemm_tn_group_accum(n - i < 8 ? n - i : 8, G, H, Kg + i, Ag + i, G, Bg + i, H, Cg + i, H,
-                                                !exact_f32, stream);
+                                                exact_f32 ? 0 : (wide ? 2 : 1), stream);
                 if (rc) return rc;
             }
             for (int l = 1; l < L && do_wx; ++l) {
@@ -2258,7 +2259,8 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
         if (do_table) {  // dTable0 += OneHot[rows]^T . dG_0[rows]   (see onehot_kernel)
             rc = arcvae_gemm_f32(1, 0, V, G, nt * B, onehot_ws + (long)t_lo * B * Vp, Vp, dG + (long)t_lo * B * G, G,
                                  dtable_ws, G, nullptr,
-                                 ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | (exact_f32 ? ARCVAE_GEMM_TILE64 : 0), stream);
+                                 ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | (exact_f32 ? ARCVAE_GEMM_TILE64 : 0) |
+                                     (wide ? ARCVAE_GEMM_TILE_WIDE : 0), stream);
             if (rc) return rc;
         }
     }

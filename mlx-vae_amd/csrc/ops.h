@@ -11,10 +11,11 @@
 #define ARCVAE_GEMM_TILE64 16   /* force 64x64 tiles (tuning / tests) */
 #define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
 #define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */
+#define ARCVAE_GEMM_TILE_WIDE 128 /* split-bf16 TN path: 128-row tile (the caller knows no persistent sweep is resident) */
 
 // internal (C++ linkage): grouped weight-gradient GEMMs, see gemm.hip
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
-                               const float* const* B, int ldb, float* const* C, int ldc, bool allow_split,
+                               const float* const* B, int ldb, float* const* C, int ldc, int allow_split,
                                hipStream_t stream);
 
 // internal (C++ linkage): two skinny products in one launch, see gemm.hip
