@@ -78,6 +78,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="default 64 (512 with --config big)")
     ap.add_argument("--config", choices=["default", "big"], default="default",
                     help="default = BASELINE.json configs[1]; big = configs[2] (H512 Z256 L4, bs 512: MFMA-bound regime)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = the parity path (headline); bf16 = throughput mode (bf16 operands, f32 accumulate: "
+                         "SURVEY 8(d) Config 2), reported with dtype bf16 and never as the headline")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mode", choices=["auto", "graph", "eager", "segments"], default="auto",
                     help="launch mode: one multi-stream hipGraph, eager launches, or per-stream graph segments")
@@ -243,7 +246,7 @@ def main(argv=None):
             st.grad.zero_()
             st.adam_m.zero_()
             st.adam_v.zero_()
-        eng_ = E.StepEngine(enc, dec, dims)
+        eng_ = E.StepEngine(enc, dec, dims, precision=args.precision)
         eng_.mode = mode
         ws_ = eng_.workspace(rows, T, train=True)
         if trace:
@@ -398,7 +401,7 @@ def main(argv=None):
             "value": seqs, "unit": "sequences/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if use_dp else 1,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"{wl_name}, bs {B}/GPU, T 128, tf 0.9, "
                                    f"beta 0 (epoch-0 schedule), fwd+bwd+Adam ({wl_ref})",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",

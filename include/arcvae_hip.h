@@ -42,6 +42,15 @@ extern "C" {
 #define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
 #define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */
 #define ARCVAE_GEMM_TILE_WIDE 128 /* split-bf16 TN path: 128-row tile (no persistent sweep resident beside it) */
+#define ARCVAE_GEMM_BF16 256      /* throughput mode: operands rounded to bf16 (RNE), f32 accumulate on v_mfma_f32_32x32x16_bf16;
+                                   * NOT a parity path (SURVEY.md section 8(d) Config 2 "bf16-in/fp32-acc"); products with M <= 256
+                                   * rows on the dependent chain keep the f32 skinny kernel */
+#define ARCVAE_LSTM_RETILE 1      /* arcvae_enc_lstm_backward flags bit 0: write the BPTT weight layouts first */
+#define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags bit 1: throughput mode -- bf16 operand copies and
+                                   * v_mfma_f32_16x16x32_bf16 products where the shape runs on the register-tiled step kernels
+                                   * (the MFMA-bound regime, e.g. H512 L4 bs 512); gates, cell state and accumulators stay f32 */
+#define ARCVAE_DEC_BF16 256       /* arcvae_dec_forward_dense `mode` bit 8 / arcvae_dec_backward_dense `flags` bit 8: the B*V-row
+                                   * products with ARCVAE_GEMM_BF16 */
 
 typedef void* arcvae_stream_t; /* hipStream_t */
 
@@ -69,8 +78,15 @@ int arcvae_transpose_tokens(const int32_t* src_bt, int32_t* dst_tb, int B, int T
 int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                             const float* const* Wh, const float* const* bias, float* hseq, float* hseq_t,
                             float* cseq, float* gseq, float* wt, float* wT_bwd /* optional */, int B, int T, int V,
-                            int H, int L, unsigned long long* trace /* optional diagnostic: {start,end} 100 MHz stamps
+                            int H, int L, int flags /* ARCVAE_LSTM_BF16 or 0; the same value must go to the backward */,
+                            void* h_oct /* optional, throughput mode: [L,T*B/8,H,8] bf16 "octet-major" copy of hseq
+                            (k = t*B + b in groups of 8 per row: the layout an MFMA fragment is loaded in) for
+                            arcvae_enc_lstm_wgrad; written when the tiled bf16 kernels run and B % 16 == 0 */,
+                            unsigned long long* trace /* optional diagnostic: {start,end} 100 MHz stamps
                             of launch s at trace[2s..2s+1], 2*(T+L-1) u64 */, arcvae_stream_t stream);
+/* bit 0 / bit 1: the forward / backward sweep of this shape runs on the register-tiled step kernels, i.e. ARCVAE_LSTM_BF16
+ * takes effect there and h_oct / dG_oct get written (pass them to arcvae_enc_lstm_wgrad only when both bits are set). */
+int arcvae_enc_lstm_tiled(int B, int H, int L);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
  * position read by models/encoder.py:106.  dG out [L,T,B,4H] (may alias gseq: in-place); dG_t ws [L,RS,B*4H]; dcs, dxs
@@ -78,7 +94,9 @@ int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const floa
 int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                              const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dG_t,
                              float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,
-                             int s_end, int retile, unsigned* start_signal /* optional: += 1 when the first launch of
+                             int s_end, int flags /* ARCVAE_LSTM_RETILE | ARCVAE_LSTM_BF16 */,
+                             void* dG_oct /* optional, throughput mode: [L,T*B/8,4H,8] bf16 octet-major copy of dG */,
+                             unsigned* start_signal /* optional: += 1 when the first launch of
                              this call starts (all earlier work of the stream is complete) */,
                              unsigned long long* trace /* optional diagnostic: stamps of launch s at trace[2s..2s+1],
                              2*(T+2(L-1)) u64 */, arcvae_stream_t stream);
@@ -146,12 +164,15 @@ int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* W
  * that may run on different streams: bit 0 = per-layer GEMMs and bias sums (= bits 2 | 3), bit 1 = token-table path,
  * bit 2 = dWx_l (l >= 1) and bias sums only, bit 3 = dWh_l only; bit 4 = exact-f32 tile GEMMs instead of the split-bf16
  * kernel; bit 5 = onehot_ws was written by arcvae_enc_prologue; bit 6 = the split-bf16 kernel's 128-row tile (the range
- * runs behind the sweep, no sweep block is resident).  The token-table path is linear in dtable_ws, so a
+ * runs behind the sweep, no sweep block is resident); bit 7 = throughput mode (one bf16 product per GEMM step instead of
+ * the six of the split form: not a parity path).  The token-table path is linear in dtable_ws, so a
  * time range may be given its own workspace and both `first` and `last` (zero, accumulate, fold) on any stream. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
                           const float* dG, float* dtable_ws, float* onehot_ws, float* dEmb, float* const* dWx,
                           float* const* dWh, float* const* dbias, int B, int T, int V, int E, int H, int L,
                           int t_lo, int t_hi, int first, int last, int parts /* 1 layers | 2 token table */,
+                          const void* h_oct, const void* dG_oct /* optional (both or none), with parts bit 7: the octet-major
+                          bf16 copies the sweeps of this step wrote -- the per-layer GEMMs then read those */,
                           arcvae_stream_t stream);
 
 /* ---- encoder heads + reparameterisation + latent loss ----------------------------------------
@@ -205,7 +226,7 @@ int arcvae_sum(const float* x, long n, float* out, float scale, arcvae_stream_t 
  * (hidden=None, cell=None every call, Q1) -> fc_out.  logits_t depends only on (token_t, cond_b),
  * so all B*V (row, token) pairs are evaluated at once: logits [B*V,V], lse [B*V], nxt [B*V]
  * (mode 0: first argmax(logits), decoder.py:185; mode 1: first argmax(softmax(logits/temperature)),
- * decoder_sampling.py:110-117). */
+ * decoder_sampling.py:110-117; | ARCVAE_DEC_BF16: throughput mode). */
 int arcvae_dec_forward_dense(const float* emb, const float* const* Wx, const float* const* bias,
                              const float* Wout, const float* bout, const float* cond, float* tableD,
                              float* hact, float* gpre, float* logits, float* lse, int32_t* nxt, int B, int V,
@@ -230,7 +251,8 @@ int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const fl
                               const float* Wout, const float* cond, const float* tableD, const float* hact,
                               const float* gpre, const float* dlogits, float* dh, float* dG, float* dtableD,
                               float* wcpart, float* dEmb, float* const* dWx, float* const* dbias, float* dWout,
-                              float* dbout, int B, int V, int E, int C, int H, int L, arcvae_stream_t stream);
+                              float* dbout, int B, int V, int E, int C, int H, int L, int flags /* ARCVAE_DEC_BF16 or 0 */,
+                              arcvae_stream_t stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------------
  * trainer.py:75-76,320,324: MLX optim.Adam, NO bias correction (Q7):

@@ -18,6 +18,11 @@ GEMM_ACCUMULATE = 1
 GEMM_TANH = 2
 GEMM_SPLITK = 4
 GEMM_NO_SKINNY = 8
+GEMM_BF16 = 256      # throughput mode: bf16 operands, f32 accumulate (include/arcvae_hip.h ARCVAE_GEMM_BF16)
+LSTM_RETILE = 1      # arcvae_enc_lstm_backward flags
+LSTM_BF16 = 2        # arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime)
+DEC_BF16 = 256       # arcvae_dec_forward_dense mode bit / arcvae_dec_backward_dense flags bit
+WGRAD_BF16 = 128     # arcvae_enc_lstm_wgrad parts bit
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -32,7 +37,8 @@ SIGNATURES = {
     "arcvae_abi_version": [_ip],
     "arcvae_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp],
     "arcvae_transpose_tokens": [_vp, _vp, _i, _i, _vp],
-    "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "arcvae_enc_lstm_tiled": [_i, _i, _i],
     "arcvae_enc_lstm_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_prologue": [_vp, _vp, _vp, _l, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
@@ -42,8 +48,8 @@ SIGNATURES = {
     "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_backward_fused": [_pp, _pp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _vp,
                                        _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
-    "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _i, _vp],
     "arcvae_stats_set_recon": [_vp, _i, _vp, _i, _vp],
     "arcvae_latent_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
@@ -57,7 +63,7 @@ SIGNATURES = {
     "arcvae_dec_gather_logits": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "arcvae_dec_sample_chain": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "arcvae_dec_backward_dense": [_vp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                  _pp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+                                  _pp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "arcvae_reparameterize": [_vp, _vp, _vp, _vp, _l, _vp],
     "arcvae_latent_stats": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "arcvae_ce_rows": [_vp, _vp, _vp, _l, _i, _vp],

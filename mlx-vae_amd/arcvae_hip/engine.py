@@ -66,6 +66,8 @@ class Workspace:
         V, E, H, Z, Cc, L = d.V, d.E, d.H, d.Z, d.C, d.L
         G, BV = 4 * H, B * V
         self.B, self.T = B, T
+        self.bf16 = False   # throughput mode (StepEngine(precision="bf16")): see StepEngine
+        self.bf16_parts = 0
         # inputs
         self.x = torch.zeros(B, T, **i32)
         self.x_tb = torch.zeros(T, B, **i32)
@@ -129,6 +131,12 @@ class Workspace:
             self.ddG = torch.empty(BV, G, **f32)
             self.dtableD = torch.empty(V, G, **f32)
             self.wcpart = torch.empty(V, G, max(Cc, 1), **f32)
+
+
+def _oct(ws, name: str) -> C.c_void_p:
+    """Throughput mode: the octet-major bf16 operand copies of the tiled sweeps (Workspace.h_oct / dG_oct), or null."""
+    t = getattr(ws, name, None)
+    return ptr(t) if t is not None else C.c_void_p(0)
 
 
 def _layer_ptrs(store: ParamStore, L: int, leaf: str, grad: bool = False, skip0: bool = False):
@@ -202,7 +210,8 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         if start_signal is not None:
             call("arcvae_gate_set", start_signal, 1, 1, s)
         call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
-             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, ptr(ws.trace_fwd), s)
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, _lib.LSTM_BF16 if ws.bf16_parts & 1 else 0,
+             _oct(ws, "h_oct"), ptr(ws.trace_fwd), s)
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
          ptr(enc.p("condition_fc.bias")), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
@@ -219,7 +228,8 @@ def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: in
     bs, _k2 = _layer_ptrs(dec, d.L, "bias")
     call("arcvae_dec_forward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
          ptr(dec.p("fc_out.bias")), ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.logits),
-         ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode, float(temperature), stream_ptr())
+         ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode | (_lib.DEC_BF16 if ws.bf16_parts & 2 else 0),
+         float(temperature), stream_ptr())
 
 
 def decoder_chain(ws: Workspace, d: ModelDims) -> None:
@@ -239,7 +249,7 @@ def decoder_backward(dec: ParamStore, ws: Workspace, d: ModelDims, inv_count: fl
     call("arcvae_dec_backward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
          ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.dlogits), ptr(ws.ddh), ptr(ws.ddG),
          ptr(ws.dtableD), ptr(ws.wcpart), ptr(dec.g("embedding.weight")), dwx, dbs, ptr(dec.g("fc_out.weight")),
-         ptr(dec.g("fc_out.bias")), ws.B, d.V, d.E, d.C, d.H, d.L, s)
+         ptr(dec.g("fc_out.bias")), ws.B, d.V, d.E, d.C, d.H, d.L, _lib.DEC_BF16 if ws.bf16_parts & 2 else 0, s)
 
 
 def latent_loss(ws: Workspace, d: ModelDims, free_bits: float, with_grads: bool) -> None:
@@ -439,8 +449,8 @@ class EncoderBackwardPlan:
             return
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
              2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
-             0,  # retile = 0: the forward of this step already wrote the BPTT weight layouts
-             start_signal if start_signal is not None else C.c_void_p(0), ptr(ws.trace_bwd), stream_ptr())
+             _lib.LSTM_BF16 if ws.bf16_parts & 1 else 0,  # no LSTM_RETILE: the forward of this step already wrote the BPTT weight layouts
+             _oct(ws, "dG_oct"), start_signal if start_signal is not None else C.c_void_p(0), ptr(ws.trace_bwd), stream_ptr())
 
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3, table=None) -> None:
         """Weight gradients of the time range.  `table`: token-table workspace of this call (default ws.dtable0); the
@@ -457,7 +467,11 @@ class EncoderBackwardPlan:
                      ptr(enc.p("embedding.weight")), ptr(enc.g("embedding.weight")), ptr(enc.g("lstm_layer_0.Wx")),
                      ptr(enc.g("lstm_layer_0.bias")), d.V, d.E, 4 * d.H, stream_ptr())
             return
-        if not (self.persistent and ws.B <= 64):
+        if (ws.bf16_parts & 4) and not self.persistent:
+            # throughput mode: one bf16 product per GEMM step.  Not beside a persistent sweep: there the matrix pipe is
+            # idle anyway and what counts is what fits on the sweep's SIMDs (measured at bs 64: 1.077 vs 1.03 ms)
+            parts |= _lib.WGRAD_BF16
+        elif not (self.persistent and ws.B <= 64):
             # The split-bf16 GEMM pays beside the one-row-group persistent sweep only (1.061 vs 1.083 ms at bs 64: its
             # 208 registers fit on a SIMD next to the sweep's 296, and it leaves the matrix pipe to the chain).  Beside
             # the 2-group sweep (343 registers) it cannot be resident, and beside the per-step launches the exact-f32
@@ -471,7 +485,8 @@ class EncoderBackwardPlan:
              ptr(ws.hseq), ptr(ws.dG), ptr(table if table is not None else ws.dtable0), ptr(ws.onehot),
              ptr(enc.g("embedding.weight")), self._dwx[0],
              self._dwh[0],
-             self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), parts, stream_ptr())
+             self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), parts,
+             _oct(ws, "h_oct"), _oct(ws, "dG_oct"), stream_ptr())
 
 
 def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
@@ -671,10 +686,18 @@ class StepEngine:
               "eager" plain launches; "graph" the whole step as ONE forked hipGraph (kept for comparison).
     """
 
-    def __init__(self, enc: ParamStore, dec: ParamStore, dims: ModelDims):
+    def __init__(self, enc: ParamStore, dec: ParamStore, dims: ModelDims, precision: Optional[str] = None):
         dims.validate()
         _lib.load()  # fail loudly when the extension is missing
         self.enc, self.dec, self.d = enc, dec, dims
+        # "fp32" (default): the parity path (1e-4 against the oracle).  "bf16": throughput mode (SURVEY.md section 8(d)
+        # Config 2, "bf16-in/fp32-acc") -- every matrix product off the latency-bound chain takes bf16 operands with f32
+        # accumulation: the decoder's B*V-row GEMMs, the weight-gradient GEMMs, and the LSTM sweeps where they run on the
+        # register-tiled step kernels; parameters, optimizer state, gates, cell state, losses stay f32.  Not a parity path:
+        # its tolerance is stated in tests/test_bf16_mode_gpu.py and DESIGN.md section 10b.
+        self.precision = precision or os.environ.get("ARCVAE_PRECISION", "fp32")
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.precision!r}")
         self.device = enc.device
         self._ws: Dict[Tuple[int, int, bool], Workspace] = {}
         self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
@@ -753,6 +776,15 @@ class StepEngine:
             if (B, T, True) in self._ws:  # a training workspace also serves forward-only calls
                 return self._ws[(B, T, True)]
             ws = Workspace(self.d, B, T, self.device, train)
+            ws.bf16 = self.precision == "bf16"
+            ws.bf16_parts = int(os.environ.get("ARCVAE_BF16_PARTS", "7")) if ws.bf16 else 0   # ablation: 1 sweeps, 2 decoder, 4 weight gradients
+            if (train and (ws.bf16_parts & 5) == 5 and B % 16 == 0 and os.environ.get("ARCVAE_BF16_OCT", "1") != "0"
+                    and _lib.load().arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3
+                    and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)
+                    and _lib.load().arcvae_enc_lstm_bwd_persistent_ok(B, T, self.d.H, self.d.L) != 1):
+                # bf16 copies of hseq / dG in the weight-gradient kernel's operand layout, written by the tiled sweeps
+                ws.h_oct = torch.zeros(self.d.L * T * B * self.d.H, dtype=torch.bfloat16, device=self.device)
+                ws.dG_oct = torch.zeros(self.d.L * T * B * 4 * self.d.H, dtype=torch.bfloat16, device=self.device)
             self._ws[key] = ws
             self._probe_persistent(ws)
         return self._ws[key]

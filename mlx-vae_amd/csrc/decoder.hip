@@ -338,6 +338,8 @@ extern "C" int arcvae_dec_forward_dense(const float* emb, const float* const* Wx
         return ARCVAE_ERR_ARG;
     if (B <= 0 || V <= 0 || E <= 0 || C < 0 || C > MAXC || H <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS)
         return ARCVAE_ERR_ARG;
+    const int BF = (mode & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : 0;   // throughput mode: the B*V-row products on bf16 operands
+    mode &= ~ARCVAE_DEC_BF16;
     if (mode == 1 && !(temperature > 0.f)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
         if (!Wx[l] || !bias[l]) return ARCVAE_ERR_ARG;
@@ -349,13 +351,13 @@ extern "C" int arcvae_dec_forward_dense(const float* emb, const float* const* Wx
                        bias[0], hact, B, V, E, C, H);
     for (int l = 1; l < L; ++l) {
         float* Gl = gpre + (long)(l - 1) * R * G;
-        rc = arcvae_gemm_f32(0, 1, (int)R, G, H, hact + (long)(l - 1) * R * H, H, Wx[l], H, Gl, G, bias[l], 0,
+        rc = arcvae_gemm_f32(0, 1, (int)R, G, H, hact + (long)(l - 1) * R * H, H, Wx[l], H, Gl, G, bias[l], BF,
                              stream);
         if (rc) return rc;
         hipLaunchKernelGGL(cell_zero_fwd_kernel, dim3(blocks_for(R * H)), dim3(256), 0, stream, Gl,
                            hact + (long)l * R * H, R, H);
     }
-    rc = arcvae_gemm_f32(0, 1, (int)R, V, H, hact + (long)(L - 1) * R * H, H, Wout, H, logits, V, bout, 0, stream);
+    rc = arcvae_gemm_f32(0, 1, (int)R, V, H, hact + (long)(L - 1) * R * H, H, Wout, H, logits, V, bout, BF, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_rowstats_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, logits, lse, nxt,
                        R, V, mode, temperature);
@@ -411,7 +413,7 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
                                          const float* hact, const float* gpre, const float* dlogits, float* dh,
                                          float* dG, float* dtableD, float* wcpart, float* dEmb,
                                          float* const* dWx, float* const* dbias, float* dWout, float* dbout,
-                                         int B, int V, int E, int C, int H, int L, hipStream_t stream) {
+                                         int B, int V, int E, int C, int H, int L, int flags, hipStream_t stream) {
     if (!emb || !Wx || !bias || !Wout || !cond || !tableD || !hact || !gpre || !dlogits || !dh || !dG ||
         !dtableD || !wcpart || !dEmb || !dWx || !dbias || !dWout || !dbout)
         return ARCVAE_ERR_ARG;
@@ -420,7 +422,8 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
     const int G = 4 * H;
     const long R = (long)B * V;
     const int Ri = (int)R;
-    const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK;
+    const int BF = (flags & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : 0;
+    const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | BF;
     float* dhA = dh;
     float* dhB = dh + R * H;
     const float* hTop = hact + (long)(L - 1) * R * H;
@@ -428,7 +431,7 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
     if (rc) return rc;
     rc = arcvae_colsum_accum(dlogits, Ri, V, V, dbout, 1.0f, stream);
     if (rc) return rc;
-    rc = arcvae_gemm_f32(0, 0, Ri, H, V, dlogits, V, Wout, H, dhA, H, nullptr, 0, stream);  // dh = dL Wout
+    rc = arcvae_gemm_f32(0, 0, Ri, H, V, dlogits, V, Wout, H, dhA, H, nullptr, BF, stream);  // dh = dL Wout
     if (rc) return rc;
     for (int l = L - 1; l >= 1; --l) {
         const float* Gl = gpre + (long)(l - 1) * R * G;
@@ -437,7 +440,7 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
         if (rc) return rc;
         rc = arcvae_colsum_accum(dG, Ri, G, G, dbias[l], 1.0f, stream);
         if (rc) return rc;
-        rc = arcvae_gemm_f32(0, 0, Ri, H, G, dG, G, Wx[l], H, dhB, H, nullptr, 0, stream);  // dh_{l-1} = dG Wx_l
+        rc = arcvae_gemm_f32(0, 0, Ri, H, G, dG, G, Wx[l], H, dhB, H, nullptr, BF, stream);  // dh_{l-1} = dG Wx_l
         if (rc) return rc;
         float* t = dhA; dhA = dhB; dhB = t;
     }

@@ -20,6 +20,15 @@
 
 namespace {
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_g __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned split_pk(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
 struct GemmP {
     const float* A;
     const float* B;
@@ -193,6 +202,192 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmP p) {
     gemm_tile_body<BM, BN, AK, BKC, VA, VB>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z > 1);
 }
 
+// ---- bf16-in / f32-accumulate tile GEMM (throughput mode, ARCVAE_GEMM_BF16) ----------------------------------------------
+// Same contract as gemm_tile_kernel (operands f32 in memory, any of the four layouts, bias / tanh / d-tanh / "+=" /
+// split-K epilogues), but the operands are rounded to bf16 (v_cvt_pk_bf16_f32, round to nearest even) on their way into
+// LDS and the products run on v_mfma_f32_32x32x16_bf16 with f32 accumulators: 16x the f32 matrix rate, ~3 significant
+// digits per operand.  NOT a parity path (DESIGN.md section 10b states its tolerance); chosen per call by the flag.
+// LDS image: [row][BKT + 8] bf16, k contiguous (one ds_read_b128 = a lane's 8 k of one MFMA; the 16-byte row pad keeps
+// the 8 lanes of a read group on different 16-byte slots).  A k-contiguous operand is staged by 2 x 16-byte loads per
+// lane and one ds_write_b128; a k-strided one ([K, rows] storage) by 8 loads down its column(s) -- a wave covers
+// 64 * VW consecutive rows per load -- and VW ds_write_b128.
+template <int ROWS, bool KCONTIG, int BKT>
+struct BfLoader {
+    static constexpr int LDK = BKT + 8;
+    static constexpr int VW = ROWS / 64;                    // k-strided: rows per lane
+    static constexpr int NT = KCONTIG ? (ROWS * BKT / 8) / 256 : BKT / 32;
+    float v[NT][KCONTIG ? 8 : 8 * VW];
+
+    // vector loads allowed? (k-contiguous: 16-byte rows; k-strided: VW-float groups)
+    static inline bool ok(const float* P, int ld, int rows, int K) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(P);
+        if (KCONTIG) return (a & 15) == 0 && (ld % 4) == 0 && (K % 4) == 0;
+        return (a & (4 * VW - 1)) == 0 && (ld % VW) == 0 && (rows % VW) == 0;
+    }
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int rmax, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if constexpr (KCONTIG) {
+                const int idx = tid + i * 256, r = r0 + idx / (BKT / 8), k = k0 + (idx % (BKT / 8)) * 8;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                if (r < rmax) {
+                    const float* q = P + (long)r * ld + k;
+                    if (k < kend) a = *reinterpret_cast<const float4*>(q);
+                    if (k + 4 < kend) b = *reinterpret_cast<const float4*>(q + 4);
+                }
+                v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+                v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+            } else {
+                const int o = (tid >> 6) + 4 * i, r = r0 + VW * (tid & 63);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int k = k0 + 8 * o + kk;
+                    const bool in = r < rmax && k < kend;
+                    const float* q = P + (long)k * ld + r;
+                    if constexpr (VW == 4) {
+                        const float4 t = in ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[i][kk] = t.x; v[i][8 + kk] = t.y; v[i][(VW > 2 ? 16 : 0) + kk] = t.z; v[i][(VW > 2 ? 24 : 0) + kk] = t.w;
+                    } else if constexpr (VW == 2) {
+                        const float2 t = in ? *reinterpret_cast<const float2*>(q) : make_float2(0.f, 0.f);
+                        v[i][kk] = t.x; v[i][(VW > 1 ? 8 : 0) + kk] = t.y;
+                    } else {
+                        v[i][kk] = in ? *q : 0.f;
+                    }
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(__bf16* S, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if constexpr (KCONTIG) {
+                const int idx = tid + i * 256, r = idx / (BKT / 8), o = idx % (BKT / 8);
+                const u32x4_g w = {split_pk(v[i][0], v[i][1]), split_pk(v[i][2], v[i][3]), split_pk(v[i][4], v[i][5]),
+                                   split_pk(v[i][6], v[i][7])};
+                *reinterpret_cast<u32x4_g*>(S + r * LDK + 8 * o) = w;
+            } else {
+                const int o = (tid >> 6) + 4 * i, r = VW * (tid & 63);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) {
+                    const u32x4_g w = {split_pk(v[i][8 * j + 0], v[i][8 * j + 1]), split_pk(v[i][8 * j + 2], v[i][8 * j + 3]),
+                                       split_pk(v[i][8 * j + 4], v[i][8 * j + 5]), split_pk(v[i][8 * j + 6], v[i][8 * j + 7])};
+                    *reinterpret_cast<u32x4_g*>(S + (r + j) * LDK + 8 * o) = w;
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool AK, bool BKC, int BKT>
+__device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int bx, const int by, const int bz, const bool split,
+                                               __bf16* smem) {
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32, LDK = BKT + 8;
+    __bf16* const As0 = smem;                       // As[buf] = As0 + buf * BM * LDK
+    __bf16* const Bs0 = smem + 2 * BM * LDK;        // Bs[buf] = Bs0 + buf * BN * LDK
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // One K-tile's MFMAs are 16 x shorter than in the f32 kernel, far less than a global-load round trip; what hides the
+    // loads is occupancy (~100 registers: 4 blocks per CU), not a deeper register ring: a 4-tile ring (240 registers, 2 blocks
+    // per CU) measured 216 instead of 278 TFLOP/s on [40960 x 2048] x K = 512 (profiles/r02_bf16_mode.txt).
+    BfLoader<BM, AK, BKT> la;
+    BfLoader<BN, BKC, BKT> lb;
+    const int nk = (kend - kbeg + BKT - 1) / BKT;
+    if (nk > 0) {
+        la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+        la.store(As0, tid);
+        lb.store(Bs0, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            la.load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BKT, kend, tid);
+            lb.load(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BKT, kend, tid);
+        }
+        const __bf16* as = As0 + cur * BM * LDK + (wm * WM + (lane & 31)) * LDK + 8 * (lane >> 5);
+        const __bf16* bs = Bs0 + cur * BN * LDK + (wn * WN + (lane & 31)) * LDK + 8 * (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < BKT; kk += 16) {
+            bf16x8_t a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(as + i * 32 * LDK + kk);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bs + j * 32 * LDK + kk);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            la.store(As0 + (cur ^ 1) * BM * LDK, tid);
+            lb.store(Bs0 + (cur ^ 1) * BN * LDK, tid);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * WN + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            const float bv = (p.bias && p.act != 2 && bz == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float* c = p.C + (long)row * p.ldc + col;
+                float v = acc[i][j][r] + bv;
+                if (split) {
+                    atomicAdd(c, v);
+                } else {
+                    if (p.accumulate) v += *c;
+                    if (p.act == 1) v = tanhf(v);
+                    if (p.act == 2) { const float t = p.bias[(long)row * p.ldc + col]; v *= (1.0f - t * t); }
+                    *c = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, bool AK, bool BKC, int BKT>
+__global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 bf_smem[];
+    gemm_bf16_body<BM, BN, AK, BKC, BKT>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z > 1, bf_smem);
+}
+
+template <int BM, int BN, bool AK, bool BKC, int BKT>
+void launch_bf16_tile(const GemmP& p, dim3 grid, hipStream_t s) {
+    const size_t lds = sizeof(__bf16) * 2 * (BM + BN) * (BKT + 8);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile_kernel<BM, BN, AK, BKC, BKT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_bf16_tile_kernel<BM, BN, AK, BKC, BKT>), grid, dim3(256), lds, s, p);
+}
+template <int BM, int BN, int BKT>
+bool launch_bf16_tile_t(const GemmP& p, dim3 grid, bool ak, bool bk, hipStream_t s) {
+    const bool aok = ak ? BfLoader<BM, true, BKT>::ok(p.A, p.lda, p.M, p.K) : BfLoader<BM, false, BKT>::ok(p.A, p.lda, p.M, p.K);
+    const bool bok = bk ? BfLoader<BN, true, BKT>::ok(p.B, p.ldb, p.N, p.K) : BfLoader<BN, false, BKT>::ok(p.B, p.ldb, p.N, p.K);
+    if (!aok || !bok) return false;
+    if (ak && bk) launch_bf16_tile<BM, BN, true, true, BKT>(p, grid, s);
+    else if (ak) launch_bf16_tile<BM, BN, true, false, BKT>(p, grid, s);
+    else if (bk) launch_bf16_tile<BM, BN, false, true, BKT>(p, grid, s);
+    else launch_bf16_tile<BM, BN, false, false, BKT>(p, grid, s);
+    return true;
+}
+
 // Grouped launch: up to 8 same-layout problems in ONE launch (blockIdx.z walks [problem][k-slice]); used for the
 // per-layer weight-gradient GEMMs of a BPTT chunk, which are small, independent and otherwise each pay a launch.
 #define ARCVAE_GEMM_GROUP_MAX 8
@@ -253,10 +448,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
 // four m feed the four 32-row MFMA tiles of the wave: tile i holds rows m0 + 4r + i (an interleaved row order, undone
 // in the epilogue's row index); B columns stay natural (n0 + 32j + c, dword loads: 128 contiguous bytes per half-wave),
 // so the epilogue's float atomics cover two full 128-B row segments per wave-instruction (the full-rate shape).
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_g __attribute__((ext_vector_type(4)));
 
 struct SplitTN {
     const float* A;   // [K, M]
@@ -271,9 +462,6 @@ struct SplitTNGroup {
     int n;
 };
 
-__device__ __forceinline__ unsigned split_pk(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
 // (x0, x1) -> packed bf16 pairs hi, mid, lo with x = hi + mid + lo (the two subtractions are exact in f32)
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
     hi = split_pk(x0, x1);
@@ -290,7 +478,8 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigne
 // and bf16 pieces of a 64 x 64 tile fit ~200 registers, which is what a wave may use BESIDE a persistent LSTM sweep wave
 // (296 of a SIMD's 512): the 128-row form (322 registers) can only run where no sweep block is resident, i.e. it waits
 // for the sweep's chunk to end (measured: step 1.147 vs 1.083 ms).
-template <int MI, int NJ>
+// ONE: plain bf16 operands (the hi piece only, one product): the throughput mode's weight-gradient GEMM.
+template <int MI, int NJ, bool ONE = false>
 __device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, const int by, const int bz, float* red) {
     constexpr int TT = MI * NJ;                    // 32 x 32 MFMA tiles of the block tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -330,12 +519,16 @@ __device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, co
     {                                                                                                             \
         u32x4_g ah[MI], amid[MI], al[MI], bh[NJ], bm[NJ], bl[NJ];                                                 \
         _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                           \
-            unsigned x, y, z;                                                                                     \
+            unsigned x, y = 0, z = 0;                                                                             \
             _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                      \
-                split3(ra[BUF][2 * d][i], ra[BUF][2 * d + 1][i], x, y, z); ah[i][d] = x; amid[i][d] = y; al[i][d] = z; \
+                if constexpr (ONE) x = split_pk(ra[BUF][2 * d][i], ra[BUF][2 * d + 1][i]);                        \
+                else split3(ra[BUF][2 * d][i], ra[BUF][2 * d + 1][i], x, y, z);                                   \
+                ah[i][d] = x; amid[i][d] = y; al[i][d] = z;                                                       \
             }                                                                                                     \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                      \
-                split3(rb[BUF][2 * d][j], rb[BUF][2 * d + 1][j], x, y, z); bh[j][d] = x; bm[j][d] = y; bl[j][d] = z; \
+                if constexpr (ONE) x = split_pk(rb[BUF][2 * d][j], rb[BUF][2 * d + 1][j]);                        \
+                else split3(rb[BUF][2 * d][j], rb[BUF][2 * d + 1][j], x, y, z);                                   \
+                bh[j][d] = x; bm[j][d] = y; bl[j][d] = z;                                                         \
             }                                                                                                     \
         }                                                                                                         \
         if ((K0) + 128 < kend) { SPLIT_LOAD(BUF, (K0) + 128) }                                                    \
@@ -346,11 +539,13 @@ __device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, co
             const bf16x8_t BH = __builtin_bit_cast(bf16x8_t, bh[j]), BM_ = __builtin_bit_cast(bf16x8_t, bm[j]),    \
                            BL = __builtin_bit_cast(bf16x8_t, bl[j]);                                              \
             f32x16 c = acc[i][j];                 /* small terms first */                                         \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, c, 0, 0, 0);                                      \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, c, 0, 0, 0);                                      \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BM_, c, 0, 0, 0);                                     \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BH, c, 0, 0, 0);                                      \
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BM_, c, 0, 0, 0);                                     \
+            if constexpr (!ONE) {                                                                                 \
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, c, 0, 0, 0);                                  \
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, c, 0, 0, 0);                                  \
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BM_, c, 0, 0, 0);                                 \
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BH, c, 0, 0, 0);                                  \
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BM_, c, 0, 0, 0);                                 \
+            }                                                                                                     \
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, c, 0, 0, 0);                                      \
             acc[i][j] = c;                                                                                        \
         }                                                                                                         \
@@ -409,14 +604,14 @@ __device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, co
     }
 }
 
-template <int MI, int NJ>
+template <int MI, int NJ, bool ONE = false>
 __global__ __launch_bounds__(256) void gemm_split_tn_group_kernel(SplitTNGroup g) {
     extern __shared__ __attribute__((aligned(16))) float split_red[];
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.z >= g.zoff[i + 1]) ++i;
     const SplitTN& p = g.p[i];
     if ((int)blockIdx.y * 32 * MI >= p.M || (int)blockIdx.x * 32 * NJ >= p.N) return;
-    split_tn_body<MI, NJ>(p, blockIdx.x, blockIdx.y, blockIdx.z - g.zoff[i], split_red);
+    split_tn_body<MI, NJ, ONE>(p, blockIdx.x, blockIdx.y, blockIdx.z - g.zoff[i], split_red);
 }
 
 // ARCVAE_GEMM_SPLIT (default 1): the TN "+=" GEMMs (weight gradients, one-hot token-table gradient) on the split-bf16
@@ -429,7 +624,7 @@ inline bool split_tn_ok(int M, int N, const float* A, int lda, const float* B, i
     return split_tn_enabled() && (M % 4) == 0 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && M >= 32 && N >= 16;
 }
 // n same-layout problems in one launch; K slices of `kslice` (multiple of 16) walk blockIdx.z
-int launch_split_tn_group(int n, const SplitTN* probs, bool wide, hipStream_t stream) {
+int launch_split_tn_group(int n, const SplitTN* probs, bool wide, bool one, hipStream_t stream) {
     SplitTNGroup g;
     g.n = n;
     int Mmax = 0, Nmax = 0, ztot = 0;
@@ -441,7 +636,7 @@ int launch_split_tn_group(int n, const SplitTN* probs, bool wide, hipStream_t st
     // ARCVAE_SPLIT_TILE: 2 (default) = 64 x 64 tiles (fits beside a persistent sweep), 4 = 128 x 64 everywhere;
     // `wide`: the caller knows no sweep is resident (the last chunk's GEMMs run behind the sweep): 128 x 64
     static const int mi_env = arcvae_env_int("ARCVAE_SPLIT_TILE", 2) == 4 ? 4 : 2;
-    const int mi = wide ? 4 : mi_env;
+    const int mi = (wide || one) ? 4 : mi_env;
     const int tiles = ceil_div(Mmax, 32 * mi) * ceil_div(Nmax, 64);
     for (int i = 0; i < n; ++i) {
         SplitTN& p = g.p[i];
@@ -456,13 +651,103 @@ int launch_split_tn_group(int n, const SplitTN* probs, bool wide, hipStream_t st
     for (int i = n; i < ARCVAE_SPLIT_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.zoff[i + 1] = ztot; }
     dim3 grid(ceil_div(Nmax, 64), ceil_div(Mmax, 32 * mi), ztot);
     const size_t lds = sizeof(float) * 2 * (mi * 2) * 16 * 64;                   // two accumulator images: 32 / 64 KB
-    if (mi == 4) {
+    if (one) {   // throughput mode: one bf16 product per step (its 128-row tile needs no operand pieces: 4 x 2 tiles always)
+        (void)hipFuncSetAttribute((const void*)gemm_split_tn_group_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_split_tn_group_kernel<4, 2, true>), grid, dim3(256), lds, stream, g);
+    } else if (mi == 4) {
         (void)hipFuncSetAttribute((const void*)gemm_split_tn_group_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((gemm_split_tn_group_kernel<4, 2>), grid, dim3(256), lds, stream, g);
     } else {
         hipLaunchKernelGGL((gemm_split_tn_group_kernel<2, 2>), grid, dim3(256), lds, stream, g);
     }
     return arcvae_launch_status();
+}
+
+// ---- throughput mode: weight gradients from OCTET-MAJOR bf16 copies ------------------------------------------------------
+// C[M,N] += A^T . B where the sweeps' epilogues have left bf16 copies of both operands in the layout an MFMA fragment is
+// loaded in: X_oct[k / 8][row][k % 8] (k = t * B + b, the contraction index; row = gate column or hidden unit), so a
+// lane's 8 consecutive k of one row are ONE 16-byte load and the 32 rows of a half-wave are 512 contiguous bytes -- no
+// LDS, no conversion, no transposition.  The f32-sourced forms (gemm_bf16_tile_kernel TN: 8 strided loads + cvt + LDS
+// round trip per operand piece; the split kernel's one-product form: 48 bytes of f32 per MFMA cycle and wave) reach
+// 80-210 TFLOP/s on the [4H x H] x K = T*B gradients of BASELINE.json configs[2]; here a wave owns a 128 x 128 tile
+// (16 accumulators, 8 loads per 16 MFMAs = 16 bytes per MFMA cycle), the 2 x 2 waves of a block share their A / B rows
+// through L1, and K is split over blockIdx.z with float atomics into the "+=" target.
+struct OctTN {
+    const __bf16* A;   // [K/8][M][8]
+    const __bf16* B;   // [K/8][N][8]
+    float* C;          // [M, N] row-major, +=
+    int K;             // multiple of 16
+    int kchunk;        // K per blockIdx.z slice (multiple of 16)
+};
+#define ARCVAE_OCT_GROUP_MAX 8
+struct OctTNGroup {
+    OctTN p[ARCVAE_OCT_GROUP_MAX];
+    int zoff[ARCVAE_OCT_GROUP_MAX + 1];
+    int n, M, N, ldc;
+};
+__global__ __launch_bounds__(256) void wgrad_octet_kernel(OctTNGroup g) {
+    int pi = 0;
+    while (pi + 1 < g.n && (int)blockIdx.z >= g.zoff[pi + 1]) ++pi;
+    const OctTN& p = g.p[pi];
+    const int bz = blockIdx.z - g.zoff[pi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 256 + (wave >> 1) * 128, n0 = blockIdx.x * 256 + (wave & 1) * 128;
+    if (n0 >= g.N || m0 >= g.M) return;            // (no barrier in this kernel)
+    const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    int arow[4], brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        arow[i] = min(m0 + 32 * i + r, g.M - 1);
+        brow[i] = min(n0 + 32 * i + r, g.N - 1);
+    }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    constexpr int NS = 3;
+    u32x4_g fa[NS][4], fb[NS][4];
+    auto load = [&](int st, int k0) {             // the K = 16 step at k0: octets k0/8 + h
+        const long o = (long)(k0 >> 3) + h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[st][i] = *reinterpret_cast<const u32x4_g*>(p.A + (o * g.M + arow[i]) * 8);
+            fb[st][i] = *reinterpret_cast<const u32x4_g*>(p.B + (o * g.N + brow[i]) * 8);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (kbeg + 16 * s < kend) load(s, kbeg + 16 * s);
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k = k0 + 16 * s;
+            if (k < kend) {
+                if (k + 16 * (NS - 1) < kend) load((s + NS - 1) % NS, k + 16 * (NS - 1));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[s][i]),
+                                                                            __builtin_bit_cast(bf16x8_t, fb[s][j]),
+                                                                            acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + 32 * j + r;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = m0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (row < g.M) atomicAdd(p.C + (long)row * g.ldc + col, acc[i][j][q]);
+            }
+        }
 }
 
 // Two independent skinny problems of the same layout in ONE launch (blockIdx.x walks the column tiles of the first, then
@@ -539,12 +824,41 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     p.kchunk = ((K + BK - 1) / BK) * BK;
 
     const bool ak = !transA, bk = transB != 0;
+    // throughput mode, large TN shapes (K long AND a grid of 128 x 128 tiles worth staging through LDS): the bf16 tile kernel
+    // below beats the LDS-free split kernel's one-product form, which is bound by its operand loads (207 vs 97 TFLOP/s on
+    // the [2048 x 512] x K = 65536 weight gradients of BASELINE.json configs[2])
+    const bool bf16_tile_tn = (flags & ARCVAE_GEMM_BF16) && M >= 256 && N >= 256 && K >= 2048;
     // TN "+=" with split-K allowed (weight-gradient / token-table shapes): split-bf16 kernel
+    if (!bf16_tile_tn)
     if (transA && !transB && (flags & ARCVAE_GEMM_ACCUMULATE) && (flags & ARCVAE_GEMM_SPLITK) && !bias && p.act == 0 &&
         !(flags & (ARCVAE_GEMM_TILE64 | ARCVAE_GEMM_TILE128)) && split_tn_ok(M, N, A, lda, B, ldb)) {
         SplitTN q;
         q.A = A; q.B = B; q.C = C; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.kchunk = 0;
-        return launch_split_tn_group(1, &q, (flags & ARCVAE_GEMM_TILE_WIDE) != 0, stream);
+        return launch_split_tn_group(1, &q, (flags & ARCVAE_GEMM_TILE_WIDE) != 0, (flags & ARCVAE_GEMM_BF16) != 0, stream);
+    }
+    // throughput mode: bf16 operands, f32 accumulate (everything but the minibatch-sized products on the chain, which
+    // are latency-bound: they keep the skinny f32 path below)
+    if ((flags & ARCVAE_GEMM_BF16) && !(transA == 0 && M <= 256) ) {
+        // 128 x 128 tiles when they fill the chip
+        // (for the K-long weight-gradient shapes the 64 x 64 tile with 2 K slices measured 207 TFLOP/s, the 128 x 128 tile
+        // with 20 slices 81: the float-atomic epilogue is paid per slice)
+        const bool big = M >= 128 && N >= 128 && ceil_div(M, 128) * ceil_div(N, 128) >= 256;
+        const int bm = big ? 128 : 64;
+        dim3 grid(ceil_div(N, bm), ceil_div(M, bm), 1);
+        if ((flags & ARCVAE_GEMM_SPLITK) && p.act == 0) {
+            static const int target = arcvae_env_int("ARCVAE_SPLITK_BLOCKS", 512);
+            int z = min(ceil_div(target, (int)(grid.x * grid.y)), max(1, K / 256));
+            if (z > 1) {
+                p.kchunk = ceil_div(ceil_div(K, z), 64) * 64;
+                grid.z = ceil_div(K, p.kchunk);
+                if (!p.accumulate && arcvae_zero(C, M, N, ldc, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+            }
+        }
+        // K-tile 32 (a 64-deep tile measured no better: 251 vs 278 TFLOP/s on [40960 x 2048] x K = 512)
+        const bool fits = big ? launch_bf16_tile_t<128, 128, 32>(p, grid, ak, bk, stream)
+                              : launch_bf16_tile_t<64, 64, 32>(p, grid, ak, bk, stream);
+        if (fits) return arcvae_launch_status();
+        p.kchunk = ((K + BK - 1) / BK) * BK;     // operands not vector-loadable: the f32 kernels below
     }
     // Skinny path: minibatch-sized M on the critical path.
     if (!(flags & ARCVAE_GEMM_NO_SKINNY) && ak && M <= 256 && (K % 64) == 0 && (lda % 4) == 0 &&
@@ -623,7 +937,16 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
                                const float* const* B, int ldb, float* const* C, int ldc, int allow_split,
                                hipStream_t stream) {
     if (n <= 0 || n > ARCVAE_GEMM_GROUP_MAX || M <= 0 || N <= 0) return ARCVAE_ERR_ARG;
-    if (allow_split) {   // 1 = split-bf16, 2 = split-bf16 with the 128-row tile (no sweep resident)
+    if ((allow_split & 4) && M >= 256 && N >= 256) {   // throughput mode, large outputs: one bf16 tile-kernel launch per problem
+        for (int i = 0; i < n; ++i) {
+            if (K[i] <= 0) continue;
+            const int rc = arcvae_gemm_f32(1, 0, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr,
+                                           ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_BF16, stream);
+            if (rc) return rc;
+        }
+        return ARCVAE_OK;
+    }
+    if (allow_split) {   // bit 0 = split-bf16 kernel; bit 1 = its 128-row tile (no sweep resident); bit 2 = one bf16 product (throughput mode)
         bool ok = true;
         for (int i = 0; i < n; ++i) ok = ok && K[i] > 0 && split_tn_ok(M, N, A[i], lda, B[i], ldb);
         if (ok) {
@@ -632,7 +955,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
                 q[i].A = A[i]; q[i].B = B[i]; q[i].C = C[i]; q[i].M = M; q[i].N = N; q[i].K = K[i];
                 q[i].lda = lda; q[i].ldb = ldb; q[i].ldc = ldc; q[i].kchunk = 0;
             }
-            return launch_split_tn_group(n, q, allow_split == 2, stream);
+            return launch_split_tn_group(n, q, (allow_split & 2) != 0, (allow_split & 4) != 0, stream);
         }
     }
     bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0;
@@ -668,5 +991,30 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
     dim3 grid(ceil_div(N, 64), ceil_div(M, 64), ztot);
     const unsigned pad = arcvae_side_lds_pad(2 * BK * (64 + 64 + 2 * PAD) * sizeof(float));
     hipLaunchKernelGGL((gemm_tile_group_kernel<64, 64, false, false, 4, 4>), grid, dim3(256), pad, stream, g);
+    return arcvae_launch_status();
+}
+
+// C_i[M,N] += A_i^T . B_i from octet-major bf16 operand copies (wgrad_octet_kernel), i < n <= 8, one launch.  Internal (ops.h).
+int arcvae_wgrad_octet_group(int n, int M, int N, const int* K, const void* const* A, const void* const* B,
+                             float* const* C, int ldc, hipStream_t stream) {
+    if (n <= 0 || n > ARCVAE_OCT_GROUP_MAX || M <= 0 || N <= 0 || ldc < N) return ARCVAE_ERR_ARG;
+    OctTNGroup g;
+    g.n = n; g.M = M; g.N = N; g.ldc = ldc;
+    const int tiles = ceil_div(M, 256) * ceil_div(N, 256);
+    static const int target = arcvae_env_int("ARCVAE_OCT_BLOCKS", 512);      // blocks wanted per launch (two rounds of 256 CUs)
+    int ztot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!A[i] || !B[i] || !C[i] || K[i] <= 0 || (K[i] % 16) != 0) return ARCVAE_ERR_ARG;
+        OctTN& p = g.p[i];
+        p.A = static_cast<const __bf16*>(A[i]); p.B = static_cast<const __bf16*>(B[i]); p.C = C[i]; p.K = K[i];
+        int z = max(1, min(ceil_div(target, tiles * n), K[i] / 512));        // at least 32 K = 16 steps per slice
+        p.kchunk = ceil_div(ceil_div(K[i], z), 16) * 16;
+        z = ceil_div(K[i], p.kchunk);
+        g.zoff[i] = ztot;
+        ztot += z;
+    }
+    g.zoff[n] = ztot;
+    for (int i = n; i < ARCVAE_OCT_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.zoff[i + 1] = ztot; }
+    hipLaunchKernelGGL(wgrad_octet_kernel, dim3(ceil_div(N, 256), ceil_div(M, 256), ztot), dim3(256), 0, stream, g);
     return arcvae_launch_status();
 }

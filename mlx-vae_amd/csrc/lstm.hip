@@ -46,11 +46,13 @@ struct FwdJob {
     float* ht;           // tiled copy [H/16][B][16] (operand of the next launches)
     float* c;            // [B,H]
     float* gates;        // [B,4H] post-activation i,f,g,o (saved for BPTT)
+    void* oct;           // throughput mode (optional): bf16 octet-major copy [B/8][H][8] of h for the weight-gradient kernel
 };
 struct FwdArgs {
     FwdJob job[ARCVAE_MAX_LAYERS];
     int B, H, V;
     int prio, remap;
+    int dbg;                    // timing experiments only (ARCVAE_TILE_DEBUG, bf16 tile kernels): 1 no contraction, 2 no epilogue
     unsigned long long* trace;  // diagnostic: {start, end} of block (0,0,0) in 100 MHz ticks, or null
 };
 
@@ -133,6 +135,7 @@ struct BwdJob {
     float* dcout;         // [B,H] dc_t * f_t                   (cell)
     float* out;           // cell: dG [B,4H];  xproj: dX [B,H]
     float* outt;          // cell: tiled copy of dG [4H/16][B][16] (operand of the next launches)
+    void* oct;            // throughput mode (optional, cell): bf16 octet-major copy [B/8][4H][8] of dG (weight-gradient kernel)
     int ext_ld;
     int kind;
 };
@@ -141,6 +144,7 @@ struct BwdArgs {
     BwdJob job[ARCVAE_MAX_BWD_JOBS];
     int B, H;
     int prio, remap;
+    int dbg;                    // timing experiments only (ARCVAE_TILE_DEBUG, bf16 tile kernels): 1 no contraction, 2 no epilogue
     unsigned long long* trace;
     unsigned* signal;  // or null: += 1 (agent scope) when this launch STARTS, i.e. when everything before it on the
                        // stream has completed -- the "sweep chunk done" signal of engine.Gates without a launch of its own
@@ -288,11 +292,61 @@ __device__ __forceinline__ void tile_contract(f32x4 (&acc)[MT][NT], const float*
     }
 }
 
+// ---- throughput mode (bf16 operands, f32 accumulate): the same tiles on v_mfma_f32_16x16x32_bf16 ---------------------
+// The k-chunk-major operand copies hold bf16 in 32-wide chunks ([kc][row][32]: a lane's 16-byte load is its 8 k of one
+// MFMA, one wave-instruction = 1 KB contiguous as before); everything a cell keeps (gates, c, h, the accumulators) stays
+// f32.  One chunk's MFMAs are 16 x shorter than in f32 (MT*NT x 16 cycles per K = 32), so the ring is NSB stages deep.
+typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_l __attribute__((ext_vector_type(4)));
+typedef float f32x2_l __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_l __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __bf16 to_bf16(float x) {     // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_convertvector(f32x2_l{x, 0.f}, bf16x2_l)[0];
+}
+template <int MT, int NT>
+struct TileFragB {
+    u32x4_l a[MT];
+    u32x4_l w[NT];
+};
+template <int MT, int NT>
+__device__ __forceinline__ void tile_load_b(TileFragB<MT, NT>& f, const __bf16* __restrict__ At, const int* arow, int RA,
+                                            const __bf16* __restrict__ Wt, const int* wrow, int RW, int kc, int q8) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) f.a[m] = *reinterpret_cast<const u32x4_l*>(At + ((long)kc * RA + arow[m]) * 32 + q8);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) f.w[n] = *reinterpret_cast<const u32x4_l*>(Wt + ((long)kc * RW + wrow[n]) * 32 + q8);
+}
+template <int MT, int NT, int NS>
+__device__ __forceinline__ void tile_contract_b(f32x4 (&acc)[MT][NT], const __bf16* __restrict__ At, const int* arow,
+                                                int RA, const __bf16* __restrict__ Wt, const int* wrow, int RW,
+                                                int nch, int q8) {
+    TileFragB<MT, NT> f[NS];
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nch) tile_load_b<MT, NT>(f[s], At, arow, RA, Wt, wrow, RW, s, q8);
+    for (int kc0 = 0; kc0 < nch; kc0 += NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int kn = kc0 + s + NS - 1;
+            if (kn < nch) tile_load_b<MT, NT>(f[(s + NS - 1) % NS], At, arow, RA, Wt, wrow, RW, kn, q8);
+            if (kc0 + s < nch) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_l, f[s].a[m]),
+                                                                            __builtin_bit_cast(bf16x8_l, f[s].w[n]),
+                                                                            acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+}
+
 // Forward: wave tile = 16*MT rows x 16*NT gate columns (4*NT hidden units); block = 4 waves side by side =
 // 16*MT rows x 64*NT columns.  grid (H / (16*NT), ceil(B / (16*MT)), jobs).  The pre-activations go through a
 // per-wave LDS tile so that one lane gets the four gates of one (row, unit); then the same fused cell update as
 // lstm_fwd_step_kernel.  (MT, NT) = (4, 4): 16 FLOP per byte, one block per CU at configs[2].
-template <int MT, int NT>
+template <int MT, int NT, bool BF = false>
 __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDT = 16 * NT + 1;     // LDS tile row stride
@@ -318,9 +372,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {   // throughput mode: bf16 operand copies, 32-wide chunks (H % 64 == 0)
+        constexpr int NSB = (MT * NT >= 16) ? 4 : 6;
+        const int q8 = (lane >> 4) * 8;
+        if (j.xin && !(a.dbg & 1)) tile_contract_b<MT, NT, NSB>(acc, reinterpret_cast<const __bf16*>(j.xin), arow, B,
+                                                reinterpret_cast<const __bf16*>(j.Wx), wrow, G, H >> 5, q8);
+        if (j.hprev && !(a.dbg & 1)) tile_contract_b<MT, NT, NSB>(acc, reinterpret_cast<const __bf16*>(j.hprev), arow, B,
+                                                  reinterpret_cast<const __bf16*>(j.Wh), wrow, G, H >> 5, q8);
+    } else {
     const int nch = H >> 4;
     if (j.xin) tile_contract<MT, NT, NS>(acc, j.xin, arow, B, j.Wx, wrow, G, nch, q4);
     if (j.hprev) tile_contract<MT, NT, NS>(acc, j.hprev, arow, B, j.Wh, wrow, G, nch, q4);
+    }
     // accumulators -> per-wave LDS tile [16*MT][LDT]: D[row = 4*(lane>>4) + reg][col = lane & 15]
     float* t = lds + wave * (16 * MT * LDT);
 #pragma unroll
@@ -334,6 +397,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
     // batch all loads of all pairs are issued before the first store: the output pointers may alias the inputs as far
     // as the compiler knows, so a load placed after a store would wait for it, and the token -> table-row -> cell
     // chain would be paid once per pair in sequence.
+    if constexpr (BF) { if (a.dbg & 2) return; }
     constexpr int NPAIR = MT * NT;
     constexpr int NP = NPAIR < 8 ? NPAIR : 8;
 #pragma unroll
@@ -378,7 +442,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
             float* gp = j.gates + (long)row * G + unit;
             gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
             j.h[hb] = hv;
-            j.ht[((long)(unit >> 4) * B + row) * 16 + (unit & 15)] = hv;
+            if constexpr (BF) {
+                const __bf16 hb16 = to_bf16(hv);
+                reinterpret_cast<__bf16*>(j.ht)[((long)(unit >> 5) * B + row) * 32 + (unit & 31)] = hb16;
+                if (j.oct) reinterpret_cast<__bf16*>(j.oct)[((long)(row >> 3) * H + unit) * 8 + (row & 7)] = hb16;
+            } else {
+                j.ht[((long)(unit >> 4) * B + row) * 16 + (unit & 15)] = hv;
+            }
             j.c[hb] = c;
         }
     }
@@ -387,7 +457,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
 
 // BPTT: block = 16*MT rows x 128 hidden units (wave w: units [32w, 32w+32)), K = 4H.  grid (ceil(H/128),
 // ceil(B / (16*MT)), jobs).  An accumulator element IS one (row, unit): the cell epilogue runs on the registers.
-template <int MT>
+template <int MT, bool BF = false>
 __global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
     arcvae_set_prio(a.prio);
     const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
@@ -411,8 +481,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (j.src) tile_contract<MT, 2, 4>(acc, j.src, arow, B, j.WT, wrow, H, G >> 4, q4);
+    if constexpr (BF) {
+        if (j.src && !(a.dbg & 1)) tile_contract_b<MT, 2, 6>(acc, reinterpret_cast<const __bf16*>(j.src), arow, B,
+                                             reinterpret_cast<const __bf16*>(j.WT), wrow, H, G >> 5, (lane >> 4) * 8);
+    } else {
+        if (j.src) tile_contract<MT, 2, 4>(acc, j.src, arow, B, j.WT, wrow, H, G >> 4, q4);
+    }
     const bool cell = j.kind == 0;
+    if constexpr (BF) { if (a.dbg & 2) { if (acc[0][0][0] == 12345.f) j.out[0] = 0.f; return; } }
     // Epilogue per 16-row group m: the 8 (row, unit) elements of a lane are loaded together (clamped indices, no
     // branch between the loads) and only then computed and stored -- see the forward tile kernel.
 #pragma unroll
@@ -455,9 +531,142 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
             j.dcout[hb] = dc * f;
             float* dp = j.out + (long)row * G + unit;
             dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+            if constexpr (BF) {
+                __bf16* tp = reinterpret_cast<__bf16*>(j.outt) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
+                const long gs = (long)(H >> 5) * B * 32;
+                const __bf16 b_i = to_bf16(d_i), b_f = to_bf16(d_f), b_g = to_bf16(d_g), b_o = to_bf16(d_o);
+                tp[0] = b_i; tp[gs] = b_f; tp[2 * gs] = b_g; tp[3 * gs] = b_o;
+                if (j.oct) {
+                    __bf16* op = reinterpret_cast<__bf16*>(j.oct) + ((long)(row >> 3) * G + unit) * 8 + (row & 7);
+                    op[0] = b_i; op[(long)H * 8] = b_f; op[(long)2 * H * 8] = b_g; op[(long)3 * H * 8] = b_o;
+                }
+            } else {
             float* tp = j.outt + ((long)(unit >> 4) * B + row) * 16 + (unit & 15);
             const long gs = (long)(H >> 4) * B * 16;
             tp[0] = d_i; tp[gs] = d_f; tp[2 * gs] = d_g; tp[3 * gs] = d_o;
+            }
+        }
+    }
+    if (tr) a.trace[1] = wall_clock64();
+}
+
+// BPTT, throughput mode, K split over the waves.  With bf16 operands the 64 x 32 wave tile above moves 48 bytes per MFMA
+// cycle and runs one block per CU on a 224-block grid: 49 us per launch at BASELINE.json configs[2], ~6 % of the bf16 MFMA
+// peak, bound by the latency of its own 384 KB of operand loads per wave.  Here a block owns 64 rows x 64 units and its
+// four waves each contract a QUARTER of K = 4H into a 64 x 64 register tile (16 accumulators, 32 bytes per MFMA cycle,
+// a third of the bytes per wave, twice the blocks); the partial tiles are exchanged through LDS (every wave ends up with
+// the 16-row group it runs the cell epilogue on).  grid (H/64, ceil(B/64), jobs).
+__global__ __launch_bounds__(256) void lstm_bwd_tile_ks_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ksred[];     // [4 src waves][3 foreign groups][16 x 4 regs][64 lanes]
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
+    if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const BwdJob& j = a.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H, G = 4 * a.H;
+    const int r = lane & 15;
+    const int row0 = blockIdx.y * 64, u0 = blockIdx.x * 64;
+    int arow[4], wrow[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        arow[m] = min(row0 + 16 * m + r, B - 1);
+        wrow[m] = min(u0 + 16 * m + r, H - 1);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j.src && !(a.dbg & 1)) {
+        const int nq = G >> 7;                            // 32-wide chunks per wave (G / 32 / 4; H % 64 == 0)
+        const __bf16* At = reinterpret_cast<const __bf16*>(j.src) + (long)wave * nq * B * 32;
+        const __bf16* Wt = reinterpret_cast<const __bf16*>(j.WT) + (long)wave * nq * H * 32;
+        tile_contract_b<4, 4, 4>(acc, At, arow, B, Wt, wrow, H, nq, (lane >> 4) * 8);
+        // exchange: group m of wave w goes to wave m (slot w' = w - (w > m) of its 3 foreign sources)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m == wave) continue;
+            float* dst = ksred + ((m * 3 + (wave - (wave > m ? 1 : 0))) * 16) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dst[(n * 4 + reg) * 64] = acc[m][n][reg];
+        }
+        __syncthreads();
+    }
+    f32x4 mine[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        mine[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m == wave) mine[n] = acc[m][n];           // wave-uniform select: my own 16-row group
+    }
+    if (j.src && !(a.dbg & 1)) {
+#pragma unroll
+        for (int sidx = 0; sidx < 3; ++sidx) {
+            const float* srcp = ksred + ((wave * 3 + sidx) * 16) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) mine[n][reg] += srcp[(n * 4 + reg) * 64];
+        }
+    }
+    const bool cell = j.kind == 0;
+    if (a.dbg & 2) { if (mine[0][0] == 12345.f) j.out[0] = 0.f; return; }
+    // cell epilogue on rows row0 + 16 wave + 4 (lane >> 4) + reg, units u0 + 16 n + r: two batches of 8 elements (loads of a
+    // batch all issued before its first store, as in lstm_bwd_tile_kernel).  Requesting all 16 elements' operands BEFORE the
+    // contraction (405 registers) measured the same 54 us per launch: the phase is bound by its stores, not its loads.
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        float gi[8], gf[8], gg[8], go[8], cv[8], cpv[8], dci[8], exv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = 2 * hf + (e >> 2), reg = e & 3;
+            const int unit = min(u0 + 16 * n + r, H - 1);
+            const int row = min(row0 + 16 * wave + (lane >> 4) * 4 + reg, B - 1);
+            const long hb = (long)row * H + unit;
+            exv[e] = j.ext ? j.ext[(long)row * j.ext_ld + unit] : 0.f;
+            if (cell) {
+                const float* gp = j.gates + (long)row * G + unit;
+                gi[e] = gp[0]; gf[e] = gp[H]; gg[e] = gp[2 * H]; go[e] = gp[3 * H];
+                cv[e] = j.c[hb];
+                cpv[e] = j.cprev ? j.cprev[hb] : 0.f;
+                dci[e] = j.dcin ? j.dcin[hb] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = 2 * hf + (e >> 2), reg = e & 3;
+            const int unit = u0 + 16 * n + r;
+            const int row = row0 + 16 * wave + (lane >> 4) * 4 + reg;
+            if (unit >= H || row >= B) continue;
+            const long hb = (long)row * H + unit;
+            const float dh = mine[n][reg] + exv[e];
+            if (!cell) {
+                j.out[hb] = dh;
+                continue;
+            }
+            const float i = gi[e], f = gf[e], g = gg[e], o = go[e];
+            const float tc = tanhf(cv[e]);
+            const float d_o = dh * tc * o * (1.f - o);
+            const float dc = dh * o * (1.f - tc * tc) + dci[e];
+            const float d_i = dc * g * i * (1.f - i);
+            const float d_f = j.cprev ? dc * cpv[e] * f * (1.f - f) : 0.f;
+            const float d_g = dc * i * (1.f - g * g);
+            j.dcout[hb] = dc * f;
+            float* dp = j.out + (long)row * G + unit;
+            dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+            const __bf16 b_i = to_bf16(d_i), b_f = to_bf16(d_f), b_g = to_bf16(d_g), b_o = to_bf16(d_o);
+            __bf16* tp = reinterpret_cast<__bf16*>(j.outt) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
+            const long gs = (long)(H >> 5) * B * 32;
+            if (!(a.dbg & 4)) { tp[0] = b_i; tp[gs] = b_f; tp[2 * gs] = b_g; tp[3 * gs] = b_o; }
+            if (j.oct && !(a.dbg & 8)) {
+                __bf16* op = reinterpret_cast<__bf16*>(j.oct) + ((long)(row >> 3) * G + unit) * 8 + (row & 7);
+                op[0] = b_i; op[(long)H * 8] = b_f; op[(long)2 * H * 8] = b_g; op[(long)3 * H * 8] = b_o;
+            }
         }
     }
     if (tr) a.trace[1] = wall_clock64();
@@ -476,14 +685,14 @@ inline int choose_tile_mt(int B, int col_blocks, int jobs) {
     return 0;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool BF = false>
 void launch_fwd_tile(const FwdArgs& a, int B, int H, int nj, hipStream_t s) {
     dim3 grid(H / (16 * NT), ceil_div(B, 16 * MT), nj);
-    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT>), grid, dim3(256), 4 * 16 * MT * (16 * NT + 1) * sizeof(float), s, a);
+    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT, BF>), grid, dim3(256), 4 * 16 * MT * (16 * NT + 1) * sizeof(float), s, a);
 }
-template <int MT>
+template <int MT, bool BF = false>
 void launch_bwd_tile(const BwdArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_bwd_tile_kernel<MT>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((lstm_bwd_tile_kernel<MT, BF>), grid, dim3(256), 0, s, a);
 }
 
 
@@ -1793,11 +2002,26 @@ inline bool hidden_ok(int H) { return H > 0 && (H % 64) == 0 && H <= 512; }
 
 }  // namespace
 
+// Throughput mode (ARCVAE_LSTM_BF16): the sweeps' operand copies and products in bf16 -- where the shape runs on the
+// register-tiled step kernels (the MFMA-bound regime, BASELINE.json configs[2]); the latency-regime kernels stay f32 (a
+// tick there is round trips, not matrix time: DESIGN.md section 10).  Forward and BPTT decide separately (their grids differ).
+static inline int fwd_tile_choice(int B, int H, int L) {
+    int tile_mt = choose_tile_mt(B, H / 32, L);
+    const int tile_env = arcvae_env_int("ARCVAE_STEP_TILE", -1);
+    if (tile_env == 44 || (tile_mt == 4 && tile_env != 4 && ceil_div(B, 64) * (H / 64) * L >= 200))
+        tile_mt = 44;  // the 64 x 64 wave tile (16 FLOP per byte) when even its grid fills the chip; 44 forces it
+    return tile_mt;
+}
+static inline bool fwd_bf16(int B, int H, int L, int flags) { return (flags & ARCVAE_LSTM_BF16) && fwd_tile_choice(B, H, L) != 0; }
+static inline bool bwd_bf16(int B, int H, int L, int flags) {
+    return (flags & ARCVAE_LSTM_BF16) && choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0;
+}
+
 // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz; with wT_bwd also the BPTT layouts of
 // the same weights (keeps that launch off the chain between the sweeps) -- one launch for both when the 2(2L-1) jobs
 // fit (L <= 4)
 static int tile_all_weights(const float* const* Wx, const float* const* Wh, float* wt, float* wT_bwd, int H, int L,
-                            hipStream_t stream) {
+                            bool fwd_b16, bool bwd_b16, hipStream_t stream) {
     const long wsz = (long)H * 4 * H;
     const float* src[32];
     float* dst[32];
@@ -1807,8 +2031,9 @@ static int tile_all_weights(const float* const* Wx, const float* const* Wh, floa
         float* base = pass == 0 ? wt : wT_bwd;
         if (!base) continue;                       // wt == null: only the BPTT layouts (persistent forward reads row-major)
         for (int l = 0; l < L; ++l) {
-            src[n] = Wh[l]; dst[n] = base + l * wsz; cols[n] = H; mode[n] = pass; ++n;
-            if (l > 0) { src[n] = Wx[l]; dst[n] = base + (L + l - 1) * wsz; cols[n] = H; mode[n] = pass; ++n; }
+            const int md = pass == 0 ? (fwd_b16 ? 2 : 0) : (bwd_b16 ? 3 : 1);
+            src[n] = Wh[l]; dst[n] = base + l * wsz; cols[n] = H; mode[n] = md; ++n;
+            if (l > 0) { src[n] = Wx[l]; dst[n] = base + (L + l - 1) * wsz; cols[n] = H; mode[n] = md; ++n; }
         }
     }
     for (int i = 0; i < n; i += 16) {
@@ -1816,6 +2041,14 @@ static int tile_all_weights(const float* const* Wx, const float* const* Wh, floa
         if (rc != ARCVAE_OK) return rc;
     }
     return ARCVAE_OK;
+}
+
+// bit 0: arcvae_enc_lstm_forward runs this shape on the register-tiled step kernels, bit 1: arcvae_enc_lstm_backward does
+// -- i.e. where ARCVAE_LSTM_BF16 takes effect (and the octet-major copies get written: both bits needed for the
+// weight-gradient kernel that reads them).
+extern "C" int arcvae_enc_lstm_tiled(int B, int H, int L) {
+    if (B <= 0 || L <= 0 || !hidden_ok(H)) return 0;
+    return (fwd_tile_choice(B, H, L) != 0 ? 1 : 0) | (choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0 ? 2 : 0);
 }
 
 // Reference: models/encoder.py:98-101 (L stacked nn.LSTM over the full padded sequence, Q3).
@@ -1832,7 +2065,7 @@ static int tile_all_weights(const float* const* Wx, const float* const* Wh, floa
 extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq,
                                        float* hseq_t, float* cseq, float* gseq, float* wt, float* wT_bwd, int B,
-                                       int T, int V, int H, int L, unsigned long long* trace,
+                                       int T, int V, int H, int L, int flags, void* h_oct, unsigned long long* trace,
                                        hipStream_t stream) {
     if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !hseq_t || !cseq || !gseq || !wt) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || V <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H)) return ARCVAE_ERR_ARG;
@@ -1841,19 +2074,19 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
     const long wsz = (long)H * 4 * H;
+    const bool b16 = fwd_bf16(B, H, L, flags);
     {
-        const int rc = tile_all_weights(Wx, Wh, wt, wT_bwd, H, L, stream);
+        const int rc = tile_all_weights(Wx, Wh, wt, wT_bwd, H, L, b16, bwd_bf16(B, H, L, flags), stream);
         if (rc != ARCVAE_OK) return rc;
     }
-    int tile_mt = choose_tile_mt(B, H / 32, L);
-    const int tile_env = arcvae_env_int("ARCVAE_STEP_TILE", -1);
-    if (tile_env == 44 || (tile_mt == 4 && tile_env != 4 && ceil_div(B, 64) * (H / 64) * L >= 200))
-        tile_mt = 44;  // the 64 x 64 wave tile (16 FLOP per byte) when even its grid fills the chip; 44 forces it
+    const int tile_mt = fwd_tile_choice(B, H, L);
+    const bool oct = b16 && h_oct && (B % 16) == 0;      // the octet-major copy groups 8 batch rows of one time step
     const bool step2 = !tile_mt && choose_step2(B);
     const int RS = arcvae_ring_slots(T);
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
         a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace ? trace + 2 * (long)s : nullptr;
+        a.dbg = arcvae_env_int("ARCVAE_TILE_DEBUG", 0);
         int nj = 0;
         for (int l = 0; l < L; ++l) {
             const int t = s - l;
@@ -1870,8 +2103,16 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             j.ht = hseq_t + ((long)l * RS + (t % RS)) * sH;
             j.c = cseq + l * lH + t * sH;
             j.gates = gseq + l * lG + t * sG;
+            j.oct = oct ? static_cast<char*>(h_oct) + 2 * (l * lH + t * sH) : nullptr;
         }
         for (int k = nj; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
+        if (tile_mt && b16) {
+            if (tile_mt == 44) launch_fwd_tile<4, 4, true>(a, B, H, nj, stream);
+            else if (tile_mt == 4) launch_fwd_tile<4, 2, true>(a, B, H, nj, stream);
+            else if (tile_mt == 2) launch_fwd_tile<2, 2, true>(a, B, H, nj, stream);
+            else launch_fwd_tile<1, 2, true>(a, B, H, nj, stream);
+            continue;
+        }
         if (tile_mt) {
             if (tile_mt == 44) launch_fwd_tile<4, 4>(a, B, H, nj, stream);
             else if (tile_mt == 4) launch_fwd_tile<4, 2>(a, B, H, nj, stream);
@@ -1909,7 +2150,7 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
     int rc;
     if (wT_bwd) {      // BPTT layouts for a launch-based backward of the same step (the sweep itself reads row-major weights)
-        rc = tile_all_weights(Wx, Wh, nullptr, wT_bwd, H, L, stream);
+        rc = tile_all_weights(Wx, Wh, nullptr, wT_bwd, H, L, false, false, stream);
         if (rc != ARCVAE_OK) return rc;
     }
     if (!(flags & 1)) {   // bit 0: sync_ws was re-armed by arcvae_enc_prologue
@@ -2109,8 +2350,11 @@ extern "C" int arcvae_enc_lstm_backward_fused(const float* const* Wx, const floa
 extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                         float* dG_t, float* dcs, float* dxs, float* wT, int B, int T, int H,
-                                        int L, int s_begin, int s_end, int retile, unsigned* start_signal,
+                                        int L, int s_begin, int s_end, int flags, void* dG_oct, unsigned* start_signal,
                                         unsigned long long* trace, hipStream_t stream) {
+    const int retile = flags & ARCVAE_LSTM_RETILE;
+    const bool b16 = bwd_bf16(B, H, L, flags);
+    const bool oct = b16 && dG_oct && (B % 16) == 0;
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
@@ -2127,8 +2371,8 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         int n = 0;
         for (int l = 0; l < L; ++l) {
             if (!Wh[l] || (l > 0 && !Wx[l])) return ARCVAE_ERR_ARG;
-            src[n] = Wh[l]; dst[n] = wT + l * wsz; cols[n] = H; mode[n] = 1; ++n;
-            if (l > 0) { src[n] = Wx[l]; dst[n] = wT + (L + l - 1) * wsz; cols[n] = H; mode[n] = 1; ++n; }
+            src[n] = Wh[l]; dst[n] = wT + l * wsz; cols[n] = H; mode[n] = b16 ? 3 : 1; ++n;
+            if (l > 0) { src[n] = Wx[l]; dst[n] = wT + (L + l - 1) * wsz; cols[n] = H; mode[n] = b16 ? 3 : 1; ++n; }
         }
         const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
@@ -2139,6 +2383,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
         a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace ? trace + 2 * (long)s : nullptr;
+        a.dbg = arcvae_env_int("ARCVAE_TILE_DEBUG", 0);
         a.signal = (s == s_begin) ? start_signal : nullptr;
         int nj = 0;
         for (int l = L - 1; l >= 0; --l) {
@@ -2159,6 +2404,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 j.dcout = dcs + ((long)l * RS + (t % RS)) * sH;
                 j.out = dG + l * lG + t * sG;
                 j.outt = dG_t + ((long)l * RS + (t % RS)) * sG;
+                j.oct = oct ? static_cast<char*>(dG_oct) + 2 * (l * lG + t * sG) : nullptr;
             }
             const int tx = T - 1 - (s + 1 - skew);     // xproj_l(tx): feeds cell(l, tx) at the next launch
             if (l < L - 1 && tx >= 0 && tx < T) {
@@ -2169,13 +2415,24 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 j.ext = nullptr; j.ext_ld = H;
                 j.gates = nullptr; j.c = nullptr; j.cprev = nullptr; j.dcin = nullptr; j.dcout = nullptr;
                 j.out = dxs + ((long)l * RS + (tx % RS)) * sH;
-                j.outt = nullptr;
+                j.outt = nullptr; j.oct = nullptr;
             }
         }
         if (nj == 0) continue;
         for (int k = nj; k < ARCVAE_MAX_BWD_JOBS; ++k) a.job[k] = a.job[0];
         if (tile_mt) {
             dim3 tgrid(ceil_div(H, 128), ceil_div(B, 16 * tile_mt), nj);
+            // ARCVAE_BWD_KSPLIT (default 1): the K-split 64 x 64 form where its grid fills the chip
+            if (b16 && tile_mt == 4 && arcvae_env_int("ARCVAE_BWD_KSPLIT", 1) != 0 && (H / 64) * ceil_div(B, 64) * nj >= 200) {
+                hipLaunchKernelGGL(lstm_bwd_tile_ks_kernel, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 48 * 1024, stream, a);
+                continue;
+            }
+            if (b16) {
+                if (tile_mt == 4) launch_bwd_tile<4, true>(a, tgrid, stream);
+                else if (tile_mt == 2) launch_bwd_tile<2, true>(a, tgrid, stream);
+                else launch_bwd_tile<1, true>(a, tgrid, stream);
+                continue;
+            }
             if (tile_mt == 4) launch_bwd_tile<4>(a, tgrid, stream);
             else if (tile_mt == 2) launch_bwd_tile<2>(a, tgrid, stream);
             else launch_bwd_tile<1>(a, tgrid, stream);
@@ -2208,7 +2465,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                                      const float* hseq, const float* dG, float* dtable_ws, float* onehot_ws,
                                      float* dEmb, float* const* dWx, float* const* dWh, float* const* dbias,
                                      int B, int T, int V, int E, int H, int L, int t_lo, int t_hi, int first,
-                                     int last, int parts, hipStream_t stream) {
+                                     int last, int parts, const void* h_oct, const void* dG_oct, hipStream_t stream) {
     if (!x_tb || !emb || !Wx0 || !hseq || !dG || !dtable_ws || !onehot_ws || !dEmb || !dWx || !dWh || !dbias)
         return ARCVAE_ERR_ARG;
     if (t_lo < 0 || t_hi > T || t_lo > t_hi) return ARCVAE_ERR_ARG;
@@ -2216,7 +2473,8 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     const long lH = (long)TB * H, lG = (long)TB * G;
     int rc;
     const bool do_wx = (parts & (1 | 4)) != 0, do_wh = (parts & (1 | 8)) != 0, do_table = (parts & 2) != 0;
-    const bool exact_f32 = (parts & 16) != 0, wide = (parts & 64) != 0;
+    const bool b16 = (parts & 128) != 0;                       // throughput mode: one bf16 product per GEMM step
+    const bool exact_f32 = (parts & 16) != 0 && !b16, wide = (parts & 64) != 0;
     const bool do_layers = do_wx || do_wh;
     const int Vp = (V + 3) & ~3;
     if (do_table && first) {
@@ -2246,9 +2504,22 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                     Cg[n] = dWx[l]; Kg[n] = nt * B; ++n;
                 }
             }
+            if (b16 && h_oct && dG_oct && (B % 16) == 0) {
+                // throughput mode with the octet-major bf16 copies the tiled sweeps left (same ranges, same targets)
+                const void* Ao[2 * ARCVAE_MAX_LAYERS];
+                const void* Bo[2 * ARCVAE_MAX_LAYERS];
+                for (int i = 0; i < n; ++i) {
+                    Ao[i] = static_cast<const char*>(dG_oct) + 2 * (Ag[i] - dG);
+                    Bo[i] = static_cast<const char*>(h_oct) + 2 * (Bg[i] - hseq);
+                }
+                for (int i = 0; i < n; i += 8) {
+                    rc = arcvae_wgrad_octet_group(n - i < 8 ? n - i : 8, G, H, Kg + i, Ao + i, Bo + i, Cg + i, H, stream);
+                    if (rc) return rc;
+                }
+            } else
             for (int i = 0; i < n; i += 8) {
                 rc = arcvae_gemm_tn_group_accum(n - i < 8 ? n - i : 8, G, H, Kg + i, Ag + i, G, Bg + i, H, Cg + i, H,
-                                                exact_f32 ? 0 : (wide ? 2 : 1), stream);
+                                                exact_f32 ? 0 : (1 | (wide ? 2 : 0) | (b16 ? 4 : 0)), stream);
                 if (rc) return rc;
             }
             for (int l = 1; l < L && do_wx; ++l) {
@@ -2260,7 +2531,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
             rc = arcvae_gemm_f32(1, 0, V, G, nt * B, onehot_ws + (long)t_lo * B * Vp, Vp, dG + (long)t_lo * B * G, G,
                                  dtable_ws, G, nullptr,
                                  ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | (exact_f32 ? ARCVAE_GEMM_TILE64 : 0) |
-                                     (wide ? ARCVAE_GEMM_TILE_WIDE : 0), stream);
+                                     (wide ? ARCVAE_GEMM_TILE_WIDE : 0) | (b16 ? ARCVAE_GEMM_BF16 : 0), stream);
             if (rc) return rc;
         }
     }

@@ -83,6 +83,39 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(TileJobs j, int H) {
         }
         return;
     }
+    if (j.mode[z] == 2 || j.mode[z] == 3) {
+        // throughput mode: the same two layouts in bf16 with 32-wide chunks.  mode 2 (forward): 8 consecutive k of a
+        // permuted row = two float4 reads, one 16-byte write.  mode 3 (BPTT, transposed): 8 consecutive gate rows g of one
+        // k = 8 reads (each coalesced over the lanes' consecutive k), one 16-byte write.
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        auto pk = [](float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, b2v)); };
+        __bf16* d16 = reinterpret_cast<__bf16*>(dst);
+        const long n8 = (long)4 * H * K / 8;
+        if (j.mode[z] == 2) {
+            const int k8n = K >> 3;
+            for (long i = (long)blockIdx.x * 256 + tid; i < n8; i += (long)gridDim.x * 256) {
+                const int r = (int)(i / k8n), k = (int)(i - (long)r * k8n) * 8;
+                const int gate = r / H, unit = r - gate * H;
+                const int rp = (unit >> 2) * 16 + gate * 4 + (unit & 3);
+                const float4 a = *reinterpret_cast<const float4*>(src + (long)r * K + k);
+                const float4 b = *reinterpret_cast<const float4*>(src + (long)r * K + k + 4);
+                *reinterpret_cast<u4v*>(d16 + ((long)(k >> 5) * 4 * H + rp) * 32 + (k & 31)) =
+                    u4v{pk(a.x, a.y), pk(a.z, a.w), pk(b.x, b.y), pk(b.z, b.w)};
+            }
+        } else {
+            for (long i = (long)blockIdx.x * 256 + tid; i < n8; i += (long)gridDim.x * 256) {
+                const int g0 = (int)(i / K) * 8, k = (int)(i % K);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = src[(long)(g0 + e) * K + k];
+                *reinterpret_cast<u4v*>(d16 + ((long)(g0 >> 5) * K + k) * 32 + (g0 & 31)) =
+                    u4v{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
+            }
+        }
+        return;
+    }
     const int ktiles = K >> 6, ntiles = (4 * H / 16) * ktiles;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int R = t / ktiles, k0 = (t - R * ktiles) * 64;

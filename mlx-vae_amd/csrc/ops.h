@@ -12,11 +12,21 @@
 #define ARCVAE_GEMM_TILE128 32  /* force 128x128 tiles */
 #define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */
 #define ARCVAE_GEMM_TILE_WIDE 128 /* split-bf16 TN path: 128-row tile (the caller knows no persistent sweep is resident) */
+#define ARCVAE_GEMM_BF16 256      /* throughput mode: operands rounded to bf16, f32 accumulate (not a parity path) */
+
+#define ARCVAE_LSTM_RETILE 1      /* arcvae_enc_lstm_backward flags: write the BPTT weight layouts first */
+#define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime only) */
+
+#define ARCVAE_DEC_BF16 256        /* arcvae_dec_forward_dense `mode` bit / arcvae_dec_backward_dense `flags` bit: throughput mode */
 
 // internal (C++ linkage): grouped weight-gradient GEMMs, see gemm.hip
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
                                const float* const* B, int ldb, float* const* C, int ldc, int allow_split,
                                hipStream_t stream);
+
+// internal (C++ linkage): throughput mode, weight gradients from octet-major bf16 operand copies, see gemm.hip
+int arcvae_wgrad_octet_group(int n, int M, int N, const int* K, const void* const* A, const void* const* B,
+                             float* const* C, int ldc, hipStream_t stream);
 
 // internal (C++ linkage): two skinny products in one launch, see gemm.hip
 int arcvae_gemm_skinny_pair(int transB, const int* M, const int* N, const int* K, const float* const* A, const int* lda,

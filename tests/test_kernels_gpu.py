@@ -51,6 +51,48 @@ def test_gemm(tA, tB, M, N, K, flags):
     assert rel_err(dC.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("tA,tB,M,N,K,flags", [(0, 1, 640, 384, 256, 0), (0, 0, 640, 384, 256, 2), (1, 0, 512, 256, 1000, 1 | 4),
+                                                (1, 1, 300, 130, 72, 1), (0, 1, 16384, 2048, 512, 0), (0, 0, 16384, 512, 2048, 0),
+                                                (1, 0, 2048, 512, 16384, 4), (0, 1, 1000, 80, 512, 0), (0, 0, 1000, 512, 80, 0),
+                                                (0, 1, 260, 100, 129, 0)])
+def test_bf16_mode_gemm_rounds_operands_only(tA, tB, M, N, K, flags):
+    """ARCVAE_GEMM_BF16 (throughput mode, csrc/gemm.hip gemm_bf16_tile_kernel / the one-product form of the split TN
+    kernel): the result must equal the fp64 product of the bf16-ROUNDED operands up to f32 accumulation error -- i.e.
+    rounding the operands is the only approximation -- and sit within 2^-8 * sum|a||b| of the unrounded product.  The last
+    case (K = 129: rows not 16-byte aligned) has to fall back to the f32 kernels, which the tighter bound shows."""
+    from arcvae_hip import _lib
+    rs = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    C0 = rs.standard_normal((M, N)).astype(np.float32)
+    use_bias = not (flags & 4)
+    dA, dB, dC, db = _dev(A), _dev(Bm), _dev(C0), _dev(bias)
+    _lib.gemm(bool(tA), bool(tB), M, N, K, dA, A.shape[1], dB, Bm.shape[1], dC, N, db if use_bias else None,
+              flags | _lib.GEMM_BF16 | _lib.GEMM_NO_SKINNY)
+    torch.cuda.synchronize()
+    got = dC.cpu().numpy().astype(np.float64)
+    rnd = lambda x: torch.from_numpy(x).to(torch.bfloat16).to(torch.float64).numpy()
+    opA, opB = (lambda X: X.T if tA else X), (lambda X: X.T if tB else X)
+    def finish(ref):
+        if use_bias:
+            ref = ref + bias
+        if flags & 1:
+            ref = ref + C0
+        if flags & 2:
+            ref = np.tanh(ref)
+        return ref
+    mag = np.abs(opA(A).astype(np.float64)) @ np.abs(opB(Bm).astype(np.float64)) + 1.0
+    exact = finish(opA(A).astype(np.float64) @ opB(Bm).astype(np.float64))
+    rounded = finish(opA(rnd(A)) @ opB(rnd(Bm)))
+    if K % 4:
+        assert (np.abs(got - exact) / mag).max() < 1e-6            # f32 fallback
+        return
+    assert (np.abs(got - rounded) / mag).max() < 2e-6, (np.abs(got - rounded) / mag).max()
+    assert (np.abs(got - exact) / mag).max() < 2.0 ** -8
+    assert (np.abs(got - exact) / mag).max() > 1e-5               # the bf16 path did run
+
+
 def test_gemm_strided_c():
     """C with ldc > N and B with ldb > K (the decoder's Wx0[:, :E] sub-block)."""
     from arcvae_hip import _lib

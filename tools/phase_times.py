@@ -6,9 +6,16 @@ for p in ("mlx-vae_amd", "tests", "oracle"): sys.path.insert(0, os.path.join(ROO
 import torch
 import arcvae_hip.engine as E
 from helpers import DEFAULT, HYPER, build_engine, make_case
-params, x, cond, eps, coins = make_case(DEFAULT, 64, 128, 0.9)
-eng, enc, dec = build_engine(DEFAULT, params)
-ws = eng.workspace(64, 128)
+# usage: phase_times.py [big] [bf16] [batch]
+from helpers import O
+BIG = O.Config(hidden_dim=512, latent_dim=256, num_layers=4)
+CFG = BIG if "big" in sys.argv else DEFAULT
+BS = next((int(a) for a in sys.argv[1:] if a.isdigit()), 512 if "big" in sys.argv else 64)
+params, x, cond, eps, coins = make_case(CFG, BS, 128, 0.9)
+eng, enc, dec = build_engine(CFG, params)
+if "bf16" in sys.argv:
+    eng = E.StepEngine(enc, dec, eng.d, precision="bf16")
+ws = eng.workspace(BS, 128)
 eng.set_hyper(ws, **HYPER); eng.load_inputs(ws, x, cond, eps, coins)
 for _ in range(10): eng.run_step(ws, 2e-4, True)
 torch.cuda.synchronize()

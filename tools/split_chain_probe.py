@@ -20,8 +20,8 @@ def make(B):
     rs = np.random.RandomState(B); x, cond = Bn.synth(rs, B)
     ws.x.copy_(torch.tensor(x)); ws.x_tb.copy_(torch.tensor(x).t().contiguous()); ws.table0.normal_(); ws.dcomb.normal_()
     return ws
-def fwd(ws): E.call("arcvae_enc_lstm_forward", E.ptr(ws.x_tb), E.ptr(ws.table0), wx, wh, bs, E.ptr(ws.hseq), E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), ws.B, T, V, H, L, None, E.stream_ptr())
-def bwd(ws): E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * H, E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), ws.B, T, H, L, 0, T + 2 * (L - 1), 0, None, None, E.stream_ptr())
+def fwd(ws): E.call("arcvae_enc_lstm_forward", E.ptr(ws.x_tb), E.ptr(ws.table0), wx, wh, bs, E.ptr(ws.hseq), E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), ws.B, T, V, H, L, 0, None, None, E.stream_ptr())
+def bwd(ws): E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * H, E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), ws.B, T, H, L, 0, T + 2 * (L - 1), 0, None, None, None, E.stream_ptr())
 
 def graph(fn, ws, stream):
     with torch.cuda.stream(stream):
