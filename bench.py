@@ -94,6 +94,9 @@ def parse_args(argv=None):
                     help="global batch of the strong-scaling leg (BASELINE.json configs[3]); 0 = skip the leg")
     ap.add_argument("--strong-steps", type=int, default=30)
     ap.add_argument("--strong-warmup", type=int, default=6)
+    ap.add_argument("--bf16-steps", type=int, default=100,
+                    help="timed steps of the bf16 throughput-mode leg reported NEXT TO the fp32 headline (N = 1, default "
+                         "config; 0 = skip)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the torch.distributed.run command --gpus N would start, and exit (no GPU touched)")
     return ap.parse_args(argv)
@@ -236,7 +239,7 @@ def main(argv=None):
     if mode == "auto":
         mode = "eager" if args.no_graph else "segments"
 
-    def make_engine(rows, global_rows, trace=False):
+    def make_engine(rows, global_rows, trace=False, precision=None):
         """(Re)initialise the weights and build engine, workspace and DP driver under the current ARCVAE_* knobs."""
         gen = torch.Generator().manual_seed(1234)  # identical initial weights on every rank
         enc.init_mlx_like(H, gen)
@@ -246,7 +249,7 @@ def main(argv=None):
             st.grad.zero_()
             st.adam_m.zero_()
             st.adam_v.zero_()
-        eng_ = E.StepEngine(enc, dec, dims, precision=args.precision)
+        eng_ = E.StepEngine(enc, dec, dims, precision=precision or args.precision)
         eng_.mode = mode
         ws_ = eng_.workspace(rows, T, train=True)
         if trace:
@@ -463,6 +466,37 @@ def main(argv=None):
                     f"{strong['value']:.0f} seq/s")
         if rank == 0:
             out["strong"] = strong
+    # ---- bf16 throughput-mode leg (SURVEY.md 8(d) Config 2 "bf16-in/fp32-acc"): the same workload on
+    # StepEngine(precision="bf16"), reported next to -- never instead of -- the fp32 headline.  Not a parity path.
+    if (world == 1 and args.precision == "fp32" and args.bf16_steps > 0 and args.config == "default"
+            and not args.batch_per_gpu and not args.force_dp):
+        eng = ws = None
+        torch.cuda.empty_cache()
+        eng3, ws3, dp3 = make_engine(B, B, precision="bf16")
+        w3 = max(5, args.warmup // 2)
+        step3 = stepper(eng3, ws3, dp3, make_inputs(B, w3 + args.bf16_steps, 67))
+        for i in range(w3):
+            step3(i)
+        torch.cuda.synchronize()
+        why = healthy(eng3)
+        if not why:
+            dt3, _ = timed(step3, w3, args.bf16_steps)
+            why = healthy(eng3)
+        if why:
+            out["bf16_mode"] = {"skipped": why}
+        else:
+            sc3 = ws3.scalars.cpu().numpy()
+            out["bf16_mode"] = {
+                "dtype": "bf16", "ms_per_step": 1e3 * dt3 / args.bf16_steps, "value": B * args.bf16_steps / dt3,
+                "unit": "sequences/s", "steps": args.bf16_steps, "warmup": w3,
+                "elbo": {"total": float(sc3[0]), "recon": float(sc3[1]), "kl": float(sc3[2])},
+                "what": "decoder B*V-row GEMMs on bf16 operands with f32 accumulation; at this shape the LSTM sweeps stay on "
+                        "the persistent f32 kernels (a tick is L2 round trips, not matrix time) and so do the weight-gradient "
+                        "GEMMs beside them: the mode pays in the MFMA-bound regime (--config big --precision bf16)",
+                "tolerance": "loss 2e-2, gradients 8e-2 relative L2 / cosine > 0.995 vs the fp64 oracle "
+                             "(tests/test_bf16_mode_gpu.py); NOT the 1e-4 parity path"}
+            log(f"bf16 mode: {out['bf16_mode']['ms_per_step']:.3f} ms/step, {out['bf16_mode']['value']:.0f} seq/s")
+        del step3, eng3, ws3
     if rank == 0:
         if args.cpu_steps > 0 and args.config == "default" and world == 1:   # the CPU baseline is an N = 1 figure
             log(f"cpu baseline on {host_cores()} host cores")

@@ -49,6 +49,10 @@ extern "C" {
 #define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags bit 1: throughput mode -- bf16 operand copies and
                                    * v_mfma_f32_16x16x32_bf16 products where the shape runs on the register-tiled step kernels
                                    * (the MFMA-bound regime, e.g. H512 L4 bs 512); gates, cell state and accumulators stay f32 */
+#define ARCVAE_PERSIST_BF16 2     /* arcvae_enc_lstm_forward_persistent flags bit 1 / arcvae_enc_lstm_backward_persistent_rs flags
+                                   * bit 1: throughput mode for the persistent sweeps -- the 4x4 MFMA blocks (H 256, B <= 64
+                                   * forward, B <= 128 BPTT) on v_mfma_f32_4x4x4_16b_bf16, weights and h / dG rounded to bf16
+                                   * on their way into the instruction */
 #define ARCVAE_DEC_BF16 256       /* arcvae_dec_forward_dense `mode` bit 8 / arcvae_dec_backward_dense `flags` bit 8: the B*V-row
                                    * products with ARCVAE_GEMM_BF16 */
 
@@ -113,7 +117,7 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
 int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L);
 /* (the sweep reads the row-major Wx / Wh themselves: no k-chunk-major copy.  wT_bwd, optional: also write the BPTT
  * layouts for a launch-based arcvae_enc_lstm_backward(retile = 0) of the same step.  flags bit 0: sync_ws has been
- * re-armed by arcvae_enc_prologue.) */
+ * re-armed by arcvae_enc_prologue; bit 1: ARCVAE_PERSIST_BF16.) */
 int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
                                        float* gseq, float* wT_bwd, float* comb /* optional [B,2H]: its first H columns
@@ -143,7 +147,8 @@ int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* 
                                            const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
                                            float* dxs, float* part_ws, unsigned* sync_ws, unsigned* start_signal, int B,
                                            int T, int H, int L, int s_begin, int s_end, int chunk_index,
-                                           unsigned long long* trace, arcvae_stream_t stream);
+                                           int flags /* ARCVAE_PERSIST_BF16 or 0 */, unsigned long long* trace,
+                                           arcvae_stream_t stream);
 /* The reduce-scatter sweep with the stack's weight gradients formed INSIDE the kernel: replaces
  * arcvae_enc_lstm_backward_persistent_rs + the per-layer GEMMs / bias sums / token segment-sum of arcvae_enc_lstm_wgrad
  * for the same ticks.  "+=" into dWh[l], dWx[l] (l >= 1), dbias[l] (l >= 1); the layer-0 input side arrives as

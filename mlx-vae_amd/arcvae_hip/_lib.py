@@ -21,6 +21,7 @@ GEMM_NO_SKINNY = 8
 GEMM_BF16 = 256      # throughput mode: bf16 operands, f32 accumulate (include/arcvae_hip.h ARCVAE_GEMM_BF16)
 LSTM_RETILE = 1      # arcvae_enc_lstm_backward flags
 LSTM_BF16 = 2        # arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime)
+PERSIST_BF16 = 2     # arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags: throughput mode (4x4x4 bf16 blocks)
 DEC_BF16 = 256       # arcvae_dec_forward_dense mode bit / arcvae_dec_backward_dense flags bit
 WGRAD_BF16 = 128     # arcvae_enc_lstm_wgrad parts bit
 
@@ -45,7 +46,7 @@ SIGNATURES = {
     "arcvae_enc_lstm_bwd_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_rs_ok": [_i, _i, _i, _i],
-    "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_backward_fused": [_pp, _pp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _vp,
                                        _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -197,7 +197,8 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         need_wT = hasattr(ws, "wT") and not bptt_reduce_scatter_ok(ws, d)
         call("arcvae_enc_lstm_forward_persistent", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq),
              ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wT) if need_wT else C.c_void_p(0), ptr(ws.comb), ptr(ws.psync),
-             start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L, 1, ptr(ws.trace_fwd), s)
+             start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L,
+             1 | (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0), ptr(ws.trace_fwd), s)
     else:
         comb_ready = 0
         if zero_grad:
@@ -439,7 +440,8 @@ class EncoderBackwardPlan:
             # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
             call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
                  ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), ptr(ws.psync), sig,
-                 ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, ptr(ws.trace_bwd), stream_ptr())
+                 ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, _lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0,
+                 ptr(ws.trace_bwd), stream_ptr())
             return
         if _lib.load().arcvae_enc_lstm_bwd_persistent_ok(ws.B, ws.T, d.H, d.L) == 1:
             # latency regime: one persistent launch per chunk (csrc/lstm.hip: lstm_bwd_persist_kernel)

@@ -989,6 +989,15 @@ __device__ __forceinline__ unsigned ps_xcc_id() {
     return v & 0xf;
 }
 
+typedef short s16x4_l __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_l __attribute__((ext_vector_type(2)));
+// four f32 -> four packed bf16 (round to nearest even, two v_cvt_pk_bf16_f32): the operand of v_mfma_f32_4x4x4_16b_bf16
+__device__ __forceinline__ s16x4_l pk4_bf16(f32x4 v) {
+    const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_l{v.x, v.y}, bf16x2_l));
+    const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_l{v.z, v.w}, bf16x2_l));
+    return __builtin_bit_cast(s16x4_l, u32x2_l{lo, hi});
+}
+
 constexpr bool persist_wreg(int NT, int LL) { return (2 * LL - 1) * (2 * NT) * NT <= 32; }
 
 // MF = 1 (H = 256, at most 8 rows per XCD, L <= 2): the contraction on v_mfma_f32_4x4x1 blocks instead of 16x16x4 tiles.
@@ -1001,6 +1010,10 @@ constexpr bool persist_wreg(int NT, int LL) { return (2 * LL - 1) * (2 * NT) * N
 template <int NT, int LL, int RT, int MF = 0>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
 __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     static_assert(MF == 0 || (NT == 2 && RT == 1 && LL <= 2), "4x4x1 form: H = 256, one row tile, L <= 2");
+    // MF = 2 (throughput mode, ARCVAE_PERSIST_BF16): the same blocks on v_mfma_f32_4x4x4_16b_bf16 -- a lane's four consecutive
+    // k (one 16-byte load of h, one float4 of its weight column) are ONE instruction instead of four: 48 instead of 192
+    // matrix instructions per wave and tick, weights in 96 instead of 192 VGPRs (packed bf16), h and the weights rounded
+    // to bf16 (round to nearest even) on their way into the instruction; accumulators, gates, c and the stored h stay f32.
     constexpr int CW = 16 * NT;          // gate columns per CU
     constexpr int UW = 4 * NT;           // hidden units per CU
     constexpr int NCH = 8 * NT;          // 16-wide k-chunks of a source (H / 16)
@@ -1044,9 +1057,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     const int r = lane & 15, q4 = (lane >> 4) * 4;
     const int rg = lane >> 5, cg = (lane >> 2) & 7, ij = lane & 3;   // 4x4x1 blocks: (row group, column group), index in block
     f32x4 wr[(WREG && !MF) ? S : 1][(WREG && !MF) ? CHW : 1][(WREG && !MF) ? NT : 1];
-    f32x4 wq[MF ? S : 1][MF ? CHW : 1][MF ? 4 : 1];   // [source][16-wide k chunk of my quarter][4-group]: W[k..k+3][4cg + ij]
+    f32x4 wq[MF == 1 ? S : 1][MF == 1 ? CHW : 1][MF == 1 ? 4 : 1];   // [source][16-wide k chunk of my quarter][4-group]: W[k..k+3][4cg + ij]
+    s16x4_l wqb[MF == 2 ? S : 1][MF == 2 ? CHW : 1][MF == 2 ? 4 : 1];   // the same, packed bf16
     {
-        if constexpr (MF == 1) {
+        if constexpr (MF == 2) {
+#pragma unroll
+            for (int si = 0; si < S; ++si)
+#pragma unroll
+                for (int c = 0; c < CHW; ++c)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        wqb[si][c][g4] = pk4_bf16(*reinterpret_cast<const f32x4*>(wsrc(si, wave * CHW + c, role * CW + 4 * cg + ij, 4 * g4)));
+        } else if constexpr (MF == 1) {
 #pragma unroll
             for (int si = 0; si < S; ++si)
 #pragma unroll
@@ -1131,7 +1153,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             if (!s_ok) return;
         }
         if (tr) a.trace[2 * s] = wall_clock64();
-        if constexpr (MF == 1) {
+        if constexpr (MF != 0) {
             // ---- A operands: 4 consecutive k of my row per load; block cg of my row group holds k = 64w + 32m + 4cg + e
             f32x4 qx[LL][2], qh[LL][2];
 #pragma unroll
@@ -1155,20 +1177,31 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             for (int l = 0; l < LL; ++l) {
                 const int t = s - l;
                 if (t < 0 || t >= T) continue;            // block-uniform
-                f32x4 acc[4];                              // four independent chains (one per k mod 4)
+                f32x4 acc[4];                              // four independent chains (one per k mod 4; bf16 form: two, per source block parity)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (MF == 2) {
+#define PS_B1(QB, SIDX, M_, AB_) acc[(AB_) & 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(QB, wqb[MF == 2 ? (SIDX) : 0][MF == 2 ? 2 * M_ + (AB_ >> 2) : 0][MF == 2 ? (AB_ & 3) : 0], acc[(AB_) & 1], 3, AB_, 0);
+#define PS_B8(Q, SIDX, M_) { const s16x4_l qb_ = pk4_bf16(Q[l][M_]);                                                  \
+                             PS_B1(qb_, SIDX, M_, 0) PS_B1(qb_, SIDX, M_, 1) PS_B1(qb_, SIDX, M_, 2) PS_B1(qb_, SIDX, M_, 3) \
+                             PS_B1(qb_, SIDX, M_, 4) PS_B1(qb_, SIDX, M_, 5) PS_B1(qb_, SIDX, M_, 6) PS_B1(qb_, SIDX, M_, 7) }
+                    if (l > 0) { PS_B8(qx, LL + l - 1, 0) PS_B8(qx, LL + l - 1, 1) }
+                    if (t > 0) { PS_B8(qh, l, 0) PS_B8(qh, l, 1) }
+#undef PS_B8
+#undef PS_B1
+                } else {
 #define PS_Q1(Q, SIDX, M_, AB_)                                                                                          \
-                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].x, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].x, acc[0], 3, AB_, 0); \
-                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].y, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].y, acc[1], 3, AB_, 0); \
-                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].z, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].z, acc[2], 3, AB_, 0); \
-                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].w, wq[MF ? (SIDX) : 0][MF ? 2 * M_ + (AB_ >> 2) : 0][MF ? (AB_ & 3) : 0].w, acc[3], 3, AB_, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].x, wq[MF == 1 ? (SIDX) : 0][MF == 1 ? 2 * M_ + (AB_ >> 2) : 0][MF == 1 ? (AB_ & 3) : 0].x, acc[0], 3, AB_, 0); \
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].y, wq[MF == 1 ? (SIDX) : 0][MF == 1 ? 2 * M_ + (AB_ >> 2) : 0][MF == 1 ? (AB_ & 3) : 0].y, acc[1], 3, AB_, 0); \
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].z, wq[MF == 1 ? (SIDX) : 0][MF == 1 ? 2 * M_ + (AB_ >> 2) : 0][MF == 1 ? (AB_ & 3) : 0].z, acc[2], 3, AB_, 0); \
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(Q[l][M_].w, wq[MF == 1 ? (SIDX) : 0][MF == 1 ? 2 * M_ + (AB_ >> 2) : 0][MF == 1 ? (AB_ & 3) : 0].w, acc[3], 3, AB_, 0);
 #define PS_Q8(Q, SIDX, M_) PS_Q1(Q, SIDX, M_, 0) PS_Q1(Q, SIDX, M_, 1) PS_Q1(Q, SIDX, M_, 2) PS_Q1(Q, SIDX, M_, 3) \
                            PS_Q1(Q, SIDX, M_, 4) PS_Q1(Q, SIDX, M_, 5) PS_Q1(Q, SIDX, M_, 6) PS_Q1(Q, SIDX, M_, 7)
                 if (l > 0) { PS_Q8(qx, LL + l - 1, 0) PS_Q8(qx, LL + l - 1, 1) }
                 if (t > 0) { PS_Q8(qh, l, 0) PS_Q8(qh, l, 1) }
 #undef PS_Q8
 #undef PS_Q1
+                }
                 // lane (rg, cg, ij) holds rows 4rg + i (register i) of column 4cg + ij
                 float* rp = red + wave * RW + l * 16 * RT * CW + (4 * rg) * CW + 4 * cg + ij;
 #pragma unroll
@@ -1582,7 +1615,10 @@ template <int LL, bool WR, int MF, bool FW = false, int RG = 1>   // WR: the wei
 __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
     static_assert(MF == 0 || WR, "the 4x4x1 form keeps its weights in registers");
     static_assert(!FW || MF == 1, "fused weight gradients: 4x4x1 form only");
-    static_assert(RG == 1 || (MF == 1 && !FW), "row groups: 4x4x1 form, weight gradients by GEMM");
+    static_assert(RG == 1 || (MF != 0 && !FW), "row groups: 4x4 forms, weight gradients by GEMM");
+    // MF = 2 (throughput mode): the 4x4 blocks on v_mfma_f32_4x4x4_16b_bf16 -- four consecutive gate columns k per
+    // instruction (48 instead of 192 per wave and tick), the weight rows packed to bf16 in 96 VGPRs, the local gate
+    // gradients rounded to bf16 as they leave LDS; partial sums, exchange and cell epilogue stay f32.
     constexpr int DGL = LL * 16 * 32;                 // floats of one group's gate-gradient image
     const PersistBwdArgs& a = ar.b;
     constexpr int UW = 8, S = 2 * LL - 1, WS = 36;   // WS: padded row stride of the weight image (bank-conflict-free b128 reads)
@@ -1615,9 +1651,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
     // all in flight before the first LDS store (one load -> store round trip per element made a chunk launch cost 55 us).
     const int r = lane & 15, q4 = (lane >> 4) * 4;
     f32x4 wr[(WR && !MF) ? S : 1][(WR && !MF) ? 4 : 1][(WR && !MF) ? 2 : 1];
-    float wq[MF ? S : 1][MF ? 2 : 1][MF ? 32 : 1];
+    float wq[MF == 1 ? S : 1][MF == 1 ? 2 : 1][MF == 1 ? 32 : 1];
+    s16x4_l wqb[MF == 2 ? S : 1][MF == 2 ? 2 : 1][MF == 2 ? 8 : 1];     // bf16 form: W[4 k4 .. 4 k4 + 3][my unit], packed
     const int rg = lane >> 5, ug = (lane >> 2) & 7, ij = lane & 3;     // 4x4x1 blocks: (row group, unit group), index in block
-    if constexpr (MF == 1) {
+    if constexpr (MF == 2) {
+#pragma unroll
+        for (int si = 0; si < S; ++si)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int k4 = 0; k4 < 8; ++k4) {
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * k4 + e;
+                        w[e] = ar.W[si][(long)((k >> 3) * H + role * UW + (k & 7)) * H + 64 * wave + 32 * ch + 4 * ug + ij];
+                    }
+                    wqb[si][ch][k4] = pk4_bf16(w);
+                }
+    } else if constexpr (MF == 1) {
 #pragma unroll
         for (int si = 0; si < S; ++si)
 #pragma unroll
@@ -1781,7 +1833,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             const int tj = cellj ? T - 1 - (s - skj) : T - 1 - (s + 1 - skj);
             const bool actj = tj >= 0 && tj < T && (!cellj || tj < T - 1);
             const int ls = cellj ? lj : lj + 1;                         // layer whose local gradients feed this slot
-            if constexpr (MF == 1) {
+            if constexpr (MF != 0) {
                 // lane (rg, ug, ij): row 4rg + ij, units ju0 .. ju0+3 -> consumer ju0>>3, piece [row][ju0&7 ..]
                 float* pdst = pbase + (long)g * 2 * S * part_src + j * part_src + ((long)((64 * wave + 4 * ug) >> 3) * 32 + role) * 64 + (4 * rg + ij) * 8 + ((4 * ug) & 7);
                 if (actj) {
@@ -1790,16 +1842,28 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                     for (int k4 = 0; k4 < 8; ++k4)
                         bq[k4] = *reinterpret_cast<const f32x4*>(dgl + g * DGL + (ls * 16 + 4 * rg + ij) * 32 + 4 * k4);
                     f32x4 acc[2][2];      // two independent chains per unit chunk (first link: C = 0)
+                    if constexpr (MF == 2) {
+#pragma unroll
+                        for (int k4 = 0; k4 < 8; ++k4) {
+                            const s16x4_l bb = pk4_bf16(bq[k4]);
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch) {
+                                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                                acc[ch][k4 & 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(
+                                    wqb[MF == 2 ? j : 0][MF == 2 ? ch : 0][MF == 2 ? k4 : 0], bb, k4 > 1 ? acc[ch][k4 & 1] : z, 0, 0, 0);
+                            }
+                        }
+                    } else
 #pragma unroll
                     for (int k4 = 0; k4 < 8; ++k4)
 #pragma unroll
                         for (int ch = 0; ch < 2; ++ch) {
-                            const int sj = MF ? j : 0, sc = MF ? ch : 0, sk = MF ? 4 * k4 : 0;
+                            const int sj = MF == 1 ? j : 0, sc = MF == 1 ? ch : 0, sk = MF == 1 ? 4 * k4 : 0;
                             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
                             acc[ch][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + 0], bq[k4].x, k4 ? acc[ch][0] : z, 0, 0, 0);
-                            acc[ch][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF ? 1 : 0)], bq[k4].y, k4 ? acc[ch][1] : z, 0, 0, 0);
-                            acc[ch][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF ? 2 : 0)], bq[k4].z, acc[ch][0], 0, 0, 0);
-                            acc[ch][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF ? 3 : 0)], bq[k4].w, acc[ch][1], 0, 0, 0);
+                            acc[ch][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF == 1 ? 1 : 0)], bq[k4].y, k4 ? acc[ch][1] : z, 0, 0, 0);
+                            acc[ch][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF == 1 ? 2 : 0)], bq[k4].z, acc[ch][0], 0, 0, 0);
+                            acc[ch][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF == 1 ? 3 : 0)], bq[k4].w, acc[ch][1], 0, 0, 0);
                         }
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch)   // unit chunk ch: units + 32 -> consumer + 4
@@ -2171,7 +2235,11 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
 #define PS_BY_L(N_) switch (L) { case 1: PS_LAUNCH(N_, 1); break; case 2: PS_LAUNCH(N_, 2); break; case 3: PS_LAUNCH(N_, 3); break; default: PS_LAUNCH(N_, 4); break; }
     // ARCVAE_FWD_MFMA: 1 (default) = 4x4x1 blocks where the shape allows (H 256, <= 8 rows per XCD, L <= 2), 0 = 16x16x4
     if (NT == 2 && L <= 2 && a.RX <= 8 && arcvae_env_int("ARCVAE_FWD_MFMA", 1) != 0) {
-        if (L == 1) launch_persist<2, 1, 1, 1>(a, lds, stream); else launch_persist<2, 2, 1, 1>(a, lds, stream);
+        if (flags & ARCVAE_PERSIST_BF16) {   // throughput mode: the 4x4x4 bf16 form of the same blocks
+            if (L == 1) launch_persist<2, 1, 1, 2>(a, lds, stream); else launch_persist<2, 2, 1, 2>(a, lds, stream);
+        } else {
+            if (L == 1) launch_persist<2, 1, 1, 1>(a, lds, stream); else launch_persist<2, 2, 1, 1>(a, lds, stream);
+        }
     } else if (NT == 1) { PS_BY_L(1) } else if (NT == 2) { PS_BY_L(2) } else { PS_BY_L(3) }
 #undef PS_BY_L
 #undef PS_LAUNCH
@@ -2237,7 +2305,7 @@ struct FusedWgrad {
 int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* cseq, const float* gseq,
                   const float* dh_top, int ld_dh_top, float* dG, float* dcs, float* dxs, float* part_ws,
                   unsigned* sync_ws, unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
-                  int chunk_index, unsigned long long* trace, const FusedWgrad* fused, hipStream_t stream) {
+                  int chunk_index, unsigned long long* trace, const FusedWgrad* fused, int flags, hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !part_ws || !sync_ws) return ARCVAE_ERR_ARG;
     if (H != 256 || L < 1 || L > 2 || B < 1 || B > 256 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
@@ -2289,6 +2357,13 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     };
     // ARCVAE_RS_MFMA: 1 (default) = 4x4x1 blocks, 0 = 16x16x4 tiles (registers only; the LDS variant always uses 16x16x4)
     const bool mf = (wreg && arcvae_env_int("ARCVAE_RS_MFMA", 1) != 0) || fused || rgn > 1;
+    if ((flags & ARCVAE_PERSIST_BF16) && mf && !fused && rgn <= 2) {   // throughput mode: the 4x4x4 bf16 form of the same blocks
+        if (rgn == 2) {
+            if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 2, false, 2>); else launch(lstm_bwd_persist_rs_kernel<2, true, 2, false, 2>);
+        } else {
+            if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 2>); else launch(lstm_bwd_persist_rs_kernel<2, true, 2>);
+        }
+    } else
     if (rgn == 2) {
         if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 1, false, 2>); else launch(lstm_bwd_persist_rs_kernel<2, true, 1, false, 2>);
     } else if (rgn == 4) {
@@ -2312,10 +2387,10 @@ extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, co
                                                       const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                                       float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
                                                       unsigned* start_signal, int B, int T, int H, int L, int s_begin,
-                                                      int s_end, int chunk_index, unsigned long long* trace,
+                                                      int s_end, int chunk_index, int flags, unsigned long long* trace,
                                                       hipStream_t stream) {
     return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, sync_ws, start_signal, B, T, H, L,
-                         s_begin, s_end, chunk_index, trace, nullptr, stream);
+                         s_begin, s_end, chunk_index, trace, nullptr, flags, stream);
 }
 
 // The same sweep with the weight gradients of the stack formed INSIDE it (FW variant of lstm_bwd_persist_rs_kernel):
@@ -2333,7 +2408,7 @@ extern "C" int arcvae_enc_lstm_backward_fused(const float* const* Wx, const floa
     FusedWgrad f;
     f.hseq = hseq; f.x_tb = x_tb; f.dWx = dWx; f.dWh = dWh; f.dbias = dbias; f.dtable = dtable_ws; f.V = V;
     return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, sync_ws, start_signal, B, T, H, L,
-                         s_begin, s_end, chunk_index, trace, &f, stream);
+                         s_begin, s_end, chunk_index, trace, &f, 0, stream);
 }
 
 // BPTT for the stack.  Only h_{T-1} of the top layer receives an external gradient

@@ -17,6 +17,7 @@
 #define ARCVAE_LSTM_RETILE 1      /* arcvae_enc_lstm_backward flags: write the BPTT weight layouts first */
 #define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime only) */
 
+#define ARCVAE_PERSIST_BF16 2     /* arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags bit 1: throughput mode */
 #define ARCVAE_DEC_BF16 256        /* arcvae_dec_forward_dense `mode` bit / arcvae_dec_backward_dense `flags` bit: throughput mode */
 
 // internal (C++ linkage): grouped weight-gradient GEMMs, see gemm.hip
