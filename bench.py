@@ -490,9 +490,10 @@ def main(argv=None):
                 "dtype": "bf16", "ms_per_step": 1e3 * dt3 / args.bf16_steps, "value": B * args.bf16_steps / dt3,
                 "unit": "sequences/s", "steps": args.bf16_steps, "warmup": w3,
                 "elbo": {"total": float(sc3[0]), "recon": float(sc3[1]), "kl": float(sc3[2])},
-                "what": "decoder B*V-row GEMMs on bf16 operands with f32 accumulation; at this shape the LSTM sweeps stay on "
-                        "the persistent f32 kernels (a tick is L2 round trips, not matrix time) and so do the weight-gradient "
-                        "GEMMs beside them: the mode pays in the MFMA-bound regime (--config big --precision bf16)",
+                "what": "bf16 operands, f32 accumulation: the persistent sweeps' 4x4 MFMA blocks on v_mfma_f32_4x4x4_16b_bf16 "
+                        "(48 instead of 192 matrix instructions per wave and tick) and the decoder's B*V-row GEMMs; parameters, "
+                        "optimizer state, exchange, gates and cell state stay f32; the weight-gradient GEMMs beside the sweep "
+                        "keep their split-bf16 (fp32-accurate) form",
                 "tolerance": "loss 2e-2, gradients 8e-2 relative L2 / cosine > 0.995 vs the fp64 oracle "
                              "(tests/test_bf16_mode_gpu.py); NOT the 1e-4 parity path"}
             log(f"bf16 mode: {out['bf16_mode']['ms_per_step']:.3f} ms/step, {out['bf16_mode']['value']:.0f} seq/s")

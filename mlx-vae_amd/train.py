@@ -55,6 +55,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--device", type=str, default=None, help="HIP device, e.g. cuda:0 (extension)")
     ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic SELFIES-shaped rows (extension)")
     ap.add_argument("--no_progress", action="store_true", help="disable progress bars (extension)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
+                    help="fp32: the parity path (default); bf16: throughput mode -- matrix products on bf16 operands with "
+                         "f32 accumulation, parameters and optimizer state in f32 (extension; ARCVAE_PRECISION does the same)")
     return ap
 
 
@@ -71,6 +74,8 @@ def synthetic_dataset(n: int, vocab: int, max_length: int = 128):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.precision:                      # read when the step engine of the model is created (arcvae_hip/engine.py)
+        os.environ["ARCVAE_PRECISION"] = args.precision
     from mlx_data.dataloader import MoleculeDataset
     from models.vae import ARCVAE
     from trainer import ARCVAETrainerWithLoss

@@ -19,3 +19,8 @@ cp(f"{G}/bench_extra_{tag}.jsonl", f"{rnd}_bench_other_shapes.jsonl")
 cp(f"{G}/sampler_{tag}.json", f"{rnd}_sampler.json")
 cp(f"{G}/epoch_{tag}.txt", f"{rnd}_epoch_time.txt")
 cp(f"{G}/pmc_summary_{pmctag}.json", f"{rnd}_pmc_summary.json")
+# throughput mode (tools/bf16_measure.sh TAG)
+cp(f"{G}/bf16_mode_{tag}.txt", f"{rnd}_bf16_mode.txt")
+cp(f"{G}/bf16_bench_{tag}.jsonl", f"{rnd}_bf16_bench.jsonl")
+cp(first(f"{G}/prof_bigb_{tag}/*/*_kernel_stats.csv"), f"{rnd}_bf16_big_kernel_stats.csv")
+cp(first(f"{G}/prof_defb_{tag}/*/*_kernel_stats.csv"), f"{rnd}_bf16_default_kernel_stats.csv")
