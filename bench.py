@@ -97,6 +97,9 @@ def parse_args(argv=None):
     ap.add_argument("--bf16-steps", type=int, default=100,
                     help="timed steps of the bf16 throughput-mode leg reported NEXT TO the fp32 headline (N = 1, default "
                          "config; 0 = skip)")
+    ap.add_argument("--configs2-steps", type=int, default=8,
+                    help="timed steps of the BASELINE.json configs[2] legs (H512 Z256 L4, bs 512: the MFMA-bound regime) in fp32 "
+                         "and in bf16 throughput mode, reported under `other_configs` (N = 1, default config; 0 = skip)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the torch.distributed.run command --gpus N would start, and exit (no GPU touched)")
     return ap.parse_args(argv)
@@ -498,6 +501,68 @@ def main(argv=None):
                              "(tests/test_bf16_mode_gpu.py); NOT the 1e-4 parity path"}
             log(f"bf16 mode: {out['bf16_mode']['ms_per_step']:.3f} ms/step, {out['bf16_mode']['value']:.0f} seq/s")
         del step3, eng3, ws3
+    # ---- BASELINE.json configs[2] (H512 Z256 L4, bs 512, "MFMA-bound regime") in fp32 and in bf16 throughput mode: its own
+    # parameter stores, engine and inputs, timed in this process after the headline legs; never the headline.
+    if (world == 1 and args.precision == "fp32" and args.configs2_steps > 0 and args.config == "default"
+            and not args.batch_per_gpu and not args.force_dp):
+        eng = ws = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        H2, Z2, L2, B2, w2 = 512, 256, 4, 512, 3
+        dims2 = E.ModelDims(V=V, E=EMB, H=H2, Z=Z2, C=C, L=L2)
+        enc2 = ParamStore(encoder_shapes(V, EMB, H2, Z2, C, L2), dev)
+        dec2 = ParamStore(decoder_shapes(V, EMB, H2, Z2, C, L2), dev)
+        rs2 = np.random.RandomState(67)
+        xs2, cs2, es2 = [], [], []
+        for _ in range(4):
+            x2, c2 = synth(rs2, B2)
+            xs2.append(torch.tensor(x2, device=dev)); cs2.append(torch.tensor(c2, device=dev))
+            es2.append(torch.tensor(rs2.standard_normal((B2, Z2)).astype(np.float32), device=dev))
+        coins2 = torch.tensor((np.random.RandomState(4242).rand(w2 + args.configs2_steps, T) < TF_RATIO).astype(np.uint8), device=dev)
+        f_seq2 = 3 * fwd_flops_per_seq(V, EMB, H2, Z2, C, L2, T)
+        legs = {}
+        for prec in ("fp32", "bf16"):
+            gen = torch.Generator().manual_seed(1234)
+            enc2.init_mlx_like(H2, gen)
+            dec2.init_mlx_like(H2, gen)
+            enc2.p("fc_logvar.bias").fill_(0.35)
+            for st in (enc2, dec2):
+                st.grad.zero_(); st.adam_m.zero_(); st.adam_v.zero_()
+            eng4 = E.StepEngine(enc2, dec2, dims2, precision=prec)
+            eng4.mode = mode
+            ws4 = eng4.workspace(B2, T, train=True)
+            eng4.set_hyper(ws4, **HYPER)
+
+            def step4(i):
+                k = i % len(xs2)
+                ws4.x.copy_(xs2[k], non_blocking=True); ws4.cond.copy_(cs2[k], non_blocking=True)
+                ws4.eps.copy_(es2[k], non_blocking=True); ws4.coins.copy_(coins2[i], non_blocking=True)
+                eng4.run_step(ws4, LR, update=True)
+            for i in range(w2):
+                step4(i)
+            torch.cuda.synchronize()
+            why = healthy(eng4)
+            if not why:
+                dt4, _ = timed(step4, w2, args.configs2_steps)
+                why = healthy(eng4)
+            if why:
+                legs[prec] = {"skipped": why}
+            else:
+                sq = B2 * args.configs2_steps / dt4
+                legs[prec] = {"dtype": "f32" if prec == "fp32" else "bf16", "ms_per_step": 1e3 * dt4 / args.configs2_steps,
+                              "value": sq, "unit": "sequences/s", "steps": args.configs2_steps, "warmup": w2,
+                              "step_tflops_algorithmic": sq * f_seq2 / 1e12,
+                              "elbo_total": float(ws4.scalars.cpu().numpy()[0])}
+                if prec == "fp32":
+                    legs[prec]["frac_of_f32_mfma_peak"] = sq * f_seq2 / 1e12 / PEAK_F32_MFMA_TFLOPS
+                else:
+                    legs[prec]["frac_of_bf16_mfma_peak"] = sq * f_seq2 / 1e12 / 2500.0
+                    legs[prec]["note"] = "throughput mode: not a parity path (tests/test_bf16_mode_gpu.py states its tolerance)"
+                log(f"configs[2] {prec}: {legs[prec]['ms_per_step']:.2f} ms/step, {sq:.0f} seq/s")
+            del step4, eng4, ws4
+            torch.cuda.empty_cache()
+        out["other_configs"] = {"configs[2]": {"workload": "big AR-CVAE V80 E128 H512 Z256 C1 L4, bs 512/GPU, T 128, tf 0.9, "
+                                                           "fwd+bwd+Adam (BASELINE.json configs[2])", **legs}}
     if rank == 0:
         if args.cpu_steps > 0 and args.config == "default" and world == 1:   # the CPU baseline is an N = 1 figure
             log(f"cpu baseline on {host_cores()} host cores")

@@ -14,15 +14,15 @@ for a in "--precision fp32 --steps 300" "--precision bf16 --steps 300" "--precis
          "--precision fp32 --batch-per-gpu 256" "--precision bf16 --batch-per-gpu 256" \
          "--precision fp32 --batch-per-gpu 2048 --steps 30 --warmup 5" "--precision bf16 --batch-per-gpu 2048 --steps 30 --warmup 5" \
          "--config big --precision fp32 --steps 10 --warmup 3" "--config big --precision bf16 --steps 10 --warmup 3"; do
-  timeout -k 10 200 python bench.py $a --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 2>/dev/null | tee -a gpurun_out/bf16_bench_$TAG.jsonl | python -c "$show" >> $O
+  timeout -k 10 200 python bench.py $a --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 2>/dev/null | tee -a gpurun_out/bf16_bench_$TAG.jsonl | python -c "$show" >> $O
 done
 echo "== which part buys what at configs[2] (ARCVAE_BF16_PARTS: 1 sweeps, 2 decoder GEMMs, 4 weight-gradient GEMMs; 7 = all)" >> $O
 for m in 1 2 4 3 5; do
-  ARCVAE_BF16_PARTS=$m timeout -k 10 200 python bench.py --config big --precision bf16 --steps 10 --warmup 3 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 2>/dev/null | python -c "$show" | sed "s/^/parts=$m /" >> $O
+  ARCVAE_BF16_PARTS=$m timeout -k 10 200 python bench.py --config big --precision bf16 --steps 10 --warmup 3 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 2>/dev/null | python -c "$show" | sed "s/^/parts=$m /" >> $O
 done
 echo "== and at the default shape (1 = the persistent sweeps' 4x4x4 bf16 blocks, 2 = decoder GEMMs)" >> $O
 for m in 1 2; do
-  ARCVAE_BF16_PARTS=$m timeout -k 10 200 python bench.py --precision bf16 --steps 300 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 2>/dev/null | python -c "$show" | sed "s/^/parts=$m /" >> $O
+  ARCVAE_BF16_PARTS=$m timeout -k 10 200 python bench.py --precision bf16 --steps 300 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 2>/dev/null | python -c "$show" | sed "s/^/parts=$m /" >> $O
 done
 echo "== tools/bench_bf16_gemm.py: bf16-operand tile GEMM vs the exact-f32 MFMA tile GEMM (err = max |c - c_fp64| / sum|a||b|)" >> $O
 timeout -k 10 300 python tools/bench_bf16_gemm.py 2>/dev/null >> $O
@@ -34,6 +34,6 @@ for p in fp32 bf16; do
   timeout -k 10 200 python bench.py --roofline-only --precision $p 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d.get("roofline", d); print(sys.argv[1], "tick us %.3f" % r["us_per_launch"])' $p >> $O
 done
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bigb_$TAG -- python3 $R/bench.py --config big --precision bf16 --steps 5 --warmup 2 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 > $R/gpurun_out/prof_bigb_$TAG.log 2>&1; echo "prof big bf16 rc=$?"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_defb_$TAG -- python3 $R/bench.py --precision bf16 --steps 20 --warmup 5 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 > $R/gpurun_out/prof_defb_$TAG.log 2>&1; echo "prof default bf16 rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bigb_$TAG -- python3 $R/bench.py --config big --precision bf16 --steps 5 --warmup 2 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 > $R/gpurun_out/prof_bigb_$TAG.log 2>&1; echo "prof big bf16 rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_defb_$TAG -- python3 $R/bench.py --precision bf16 --steps 20 --warmup 5 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 > $R/gpurun_out/prof_defb_$TAG.log 2>&1; echo "prof default bf16 rc=$?"
 cat $R/$O

@@ -7,6 +7,6 @@ TAG=$1
 cd /tmp && export TMPDIR=/tmp
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   D=$GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$(echo $C | tr ' ' '+')
-  ARCVAE_GATES=0 timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $D -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --mode eager > $D.log 2>&1
+  ARCVAE_GATES=0 timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $D -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 --mode eager > $D.log 2>&1
   echo "$C rc=$?"
 done

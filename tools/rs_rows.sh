@@ -10,9 +10,9 @@ for lib in libarcvae_hip.so libarcvae_hip_alt.so; do
     ARCVAE_RS_MAX_B=256 timeout -k 10 200 python bench.py --roofline-only --precision $p --batch-per-gpu $b 2>/dev/null | python -c "$pr" "$lib B=$b $p RS_MAX_B=256"
   done; done
   for e in 128 256; do for p in fp32 bf16; do
-    ARCVAE_RS_MAX_B=$e timeout -k 10 200 python bench.py --precision $p --batch-per-gpu 256 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 2>/dev/null | python -c "$pr" "$lib B=256 $p RS_MAX_B=$e"
+    ARCVAE_RS_MAX_B=$e timeout -k 10 200 python bench.py --precision $p --batch-per-gpu 256 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 2>/dev/null | python -c "$pr" "$lib B=256 $p RS_MAX_B=$e"
   done; done
   for p in fp32 bf16; do
-    timeout -k 10 200 python bench.py --precision $p --batch-per-gpu 128 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 2>/dev/null | python -c "$pr" "$lib B=128 $p"
+    timeout -k 10 200 python bench.py --precision $p --batch-per-gpu 128 --cpu-steps 0 --no-roofline --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 2>/dev/null | python -c "$pr" "$lib B=128 $p"
   done
 done
