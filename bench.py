@@ -430,7 +430,7 @@ def main(argv=None):
         if nb > 1 and bw[-1, 0] > bw[0, 0]:
             per = float((bw[-1, 0] - bw[0, 0]) / (nb - 1))
             out["roofline"]["in_step_us_per_launch"] = per
-            out["roofline"]["in_step_frac"] = out["roofline"]["flop_per_launch"] / (per * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+            out["roofline"]["in_step_frac"] = out["roofline"]["flop_per_launch"] / (per * 1e-6) / 1e12 / out["roofline"]["peak"]
         log("roofline probe done")
 
     # ---- strong-scaling leg (BASELINE.json configs[3]: global batch 2048 over the N ranks; N = 1 included so that the
@@ -576,6 +576,11 @@ def main(argv=None):
     return 0
 
 
+def _lib_load():
+    from arcvae_hip import _lib
+    return _lib.load()
+
+
 def roofline_probe(eng, ws, torch):
     """Live HIP-event timing of the dominant kernel on the stream it is launched on.
 
@@ -633,7 +638,11 @@ def roofline_probe(eng, ws, torch):
     if fused:
         flops_total *= 2.0    # + dWh_l += dG_l^T.h_l[t-1] (L(T-1) of them) and dWx_l += dG_l^T.h_{l-1}[t] ((L-1)T): same count
     ach = flops_total / launches / (us * 1e-6) / 1e12
-    kernel = "lstm_bwd_persist_rs_kernel" if persistent else "lstm_bwd_step_kernel"
+    tiled = (not persistent) and bool(_lib_load().arcvae_enc_lstm_tiled(B, d.H, d.L) & 2)
+    bf16 = getattr(eng, "precision", "fp32") == "bf16" and (persistent or tiled)   # the sweep really runs bf16 blocks / tiles
+    kernel = ("lstm_bwd_persist_rs_kernel" if persistent else
+              ("lstm_bwd_tile_kernel / lstm_bwd_tile_ks_kernel" if tiled else "lstm_bwd_step_kernel"))
+    peak = 2500.0 if bf16 else PEAK_F32_MFMA_TFLOPS       # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
     # traffic: fabric-side bytes per tick / launch from the newest committed rocprofv3 --pmc summary (separate passes,
     # tools/pmc.sh; 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction) -- a profile figure, named by its file, not
     # measured in this run.  tick_model: where a tick's time goes (tools/probe_persist.hip on the same chip).
@@ -675,8 +684,10 @@ def roofline_probe(eng, ws, torch):
                 "same launches inside the last timed step (device-side stamps, side-stream GEMMs running beside "
                 "them).  `bound` names the section-8(d) denominator (f32-input MFMA peak); the LIMITER is the "
                 "dependent-chain seam (1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6")
-    return {"bound": "mfma", "limiter": "latency", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+    if bf16:
+        note += "  (throughput mode: bf16 operands, so `peak` is the dense bf16 MFMA peak; not the parity path)"
+    return {"bound": "mfma", "limiter": "latency", "kernel": kernel, "achieved": ach, "peak": peak,
+            "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
             "us_per_launch": us, "launches_per_sweep": launches,
             "flop_per_launch": flops_total / launches, "tick_model": tick_model, "note": note}
 
