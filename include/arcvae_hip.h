@@ -48,7 +48,10 @@ extern "C" {
 #define ARCVAE_LSTM_RETILE 1      /* arcvae_enc_lstm_backward flags bit 0: write the BPTT weight layouts first */
 #define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags bit 1: throughput mode -- bf16 operand copies and
                                    * v_mfma_f32_16x16x32_bf16 products where the shape runs on the register-tiled step kernels
-                                   * (the MFMA-bound regime, e.g. H512 L4 bs 512); gates, cell state and accumulators stay f32 */
+                                   * (the MFMA-bound regime, e.g. H512 L4 bs 512); gates, cell state and accumulators stay f32.
+                                   * The k-chunk-major workspaces (hseq_t, dG_t, wt, wT) then hold bf16 in 32-wide chunks --
+                                   * same pointers, half the bytes, so buffers sized for f32 are always large enough; forward
+                                   * and backward of a step must be given the same flag */
 #define ARCVAE_PERSIST_BF16 2     /* arcvae_enc_lstm_forward_persistent flags bit 1 / arcvae_enc_lstm_backward_persistent_rs flags
                                    * bit 1: throughput mode for the persistent sweeps -- the 4x4 MFMA blocks (H 256, B <= 64
                                    * forward, B <= 128 BPTT) on v_mfma_f32_4x4x4_16b_bf16, weights and h / dG rounded to bf16
