@@ -285,10 +285,7 @@ def main(argv=None):
 
         def one_step(i):
             k = i % len(xs)
-            ws_.x.copy_(xs[k], non_blocking=True)
-            ws_.cond.copy_(cs[k], non_blocking=True)
-            ws_.eps.copy_(es[k], non_blocking=True)
-            ws_.coins.copy_(coins[i], non_blocking=True)
+            eng_.load_inputs(ws_, xs[k], cs[k], es[k], coins[i])   # device-resident batch -> the step's static buffers (one launch)
             if dp_ is None:
                 eng_.run_step(ws_, LR, update=True)
             else:
@@ -535,8 +532,7 @@ def main(argv=None):
 
             def step4(i):
                 k = i % len(xs2)
-                ws4.x.copy_(xs2[k], non_blocking=True); ws4.cond.copy_(cs2[k], non_blocking=True)
-                ws4.eps.copy_(es2[k], non_blocking=True); ws4.coins.copy_(coins2[i], non_blocking=True)
+                eng4.load_inputs(ws4, xs2[k], cs2[k], es2[k], coins2[i])
                 eng4.run_step(ws4, LR, update=True)
             for i in range(w2):
                 step4(i)

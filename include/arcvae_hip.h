@@ -296,6 +296,9 @@ int arcvae_gate_wait(const unsigned* flag, unsigned* steps, unsigned stride, uns
 int arcvae_gate_set(unsigned* flag, unsigned value, int add, arcvae_stream_t stream);
 int arcvae_tile_weights(const float* const* src, float* const* dst, const int* cols, const int* mode, int n, int H,
                         arcvae_stream_t stream);
+/* n <= 8 small device-to-device copies in ONE launch (a step's inputs -- tokens, conditions, eps, coins -- were four copy
+ * launches of ~4 us each in front of every step): dst_i[0..nbytes_i) = src_i[0..nbytes_i).  HOST arrays of pointers. */
+int arcvae_copy_buffers(const void* const* src, void* const* dst, const long* nbytes, int n, arcvae_stream_t stream);
 
 #ifdef __cplusplus
 }

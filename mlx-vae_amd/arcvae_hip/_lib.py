@@ -32,6 +32,7 @@ _d = C.c_double
 _l = C.c_long
 _pp = C.POINTER(C.c_void_p)
 _ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_long)
 
 # name -> argtypes (restype is always int)
 SIGNATURES = {
@@ -79,6 +80,7 @@ SIGNATURES = {
     "arcvae_gate_wait": [_vp, _vp, C.c_uint, C.c_uint, _i, C.c_uint, _vp, _vp],
     "arcvae_gate_set": [_vp, C.c_uint, _i, _vp],
     "arcvae_tile_weights": [_pp, _pp, _ip, _ip, _i, _i, _vp],
+    "arcvae_copy_buffers": [_pp, _pp, _lp, _i, _vp],
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,6 +1,7 @@
 // HBM-bound helper kernels: column sums, small transposes, segment (token) sums, and the
 // fused un-bias-corrected Adam (reference trainer.py:75-76,320,324 -> MLX optim.Adam, Q7).
 #include "ops.h"
+#include <algorithm>
 
 namespace {
 
@@ -544,4 +545,49 @@ extern "C" int arcvae_abi_version(int* arch_gfx950) {
         }
     }
     return 1000;
+}
+
+// ---- several small device-to-device copies in ONE launch -------------------------------------------------------------
+// A step's inputs (tokens, conditions, eps, teacher-forcing coins) arrive as four buffers of 0.1-32 KB; as four copy
+// launches they are ~4 us each of launch-bound time in front of every step (profiles/r02_bench_kernel_stats.csv:
+// __amd_rocclr_copyBuffer, 5.8 calls per step).  dst_i[0..nbytes_i) = src_i[0..nbytes_i), i < n <= 8.
+namespace {
+struct CopyJobs {
+    const unsigned char* src[8];
+    unsigned char* dst[8];
+    long nbytes[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void copy_buffers_kernel(CopyJobs j) {
+    const int i = blockIdx.y;
+    if (i >= j.n) return;
+    const unsigned char* s = j.src[i];
+    unsigned char* d = j.dst[i];
+    const long nb = j.nbytes[i];
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x, gs = (long)gridDim.x * 256;
+    long done = 0;
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        const long n16 = nb >> 4;
+        for (long k = gt; k < n16; k += gs) reinterpret_cast<uint4*>(d)[k] = reinterpret_cast<const uint4*>(s)[k];
+        done = n16 << 4;
+    }
+    for (long k = done + gt; k < nb; k += gs) d[k] = s[k];
+}
+}  // namespace
+
+extern "C" int arcvae_copy_buffers(const void* const* src, void* const* dst, const long* nbytes, int n, hipStream_t stream) {
+    if (!src || !dst || !nbytes || n <= 0 || n > 8) return ARCVAE_ERR_ARG;
+    CopyJobs j;
+    j.n = n;
+    long mx = 0;
+    for (int i = 0; i < 8; ++i) {
+        const int k = i < n ? i : 0;
+        if (!src[k] || !dst[k] || nbytes[k] < 0) return ARCVAE_ERR_ARG;
+        j.src[i] = static_cast<const unsigned char*>(src[k]); j.dst[i] = static_cast<unsigned char*>(dst[k]);
+        j.nbytes[i] = nbytes[k];
+        if (i < n && nbytes[k] > mx) mx = nbytes[k];
+    }
+    const int bx = (int)std::min<long>(64, std::max<long>(1, (mx / 16 + 255) / 256));
+    hipLaunchKernelGGL(copy_buffers_kernel, dim3(bx, n), dim3(256), 0, stream, j);
+    return arcvae_launch_status();
 }

@@ -23,7 +23,7 @@ def _declared():
 
 def _ctype_of(decl: str):
     """The ctypes class a C parameter declaration must be bound with (the binding's conventions: pointer-to-pointer
-    = POINTER(c_void_p) host arrays of device pointers, int* = POINTER(c_int) host arrays, every other pointer and the
+    = POINTER(c_void_p) host arrays of device pointers, int* / long* = POINTER(c_int / c_long) host arrays, every other pointer and the
     stream = c_void_p)."""
     ty = re.sub(r"\b\w+$", "", decl).strip() if not decl.endswith("*") else decl   # drop the parameter name
     ty = ty.replace("const", "").replace(" ", "")
@@ -31,6 +31,8 @@ def _ctype_of(decl: str):
         return ctypes.POINTER(ctypes.c_void_p)
     if ty == "int*":
         return ctypes.POINTER(ctypes.c_int)
+    if ty == "long*":
+        return ctypes.POINTER(ctypes.c_long)
     if "*" in ty or ty == "arcvae_stream_t":
         return ctypes.c_void_p
     return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,

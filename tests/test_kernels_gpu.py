@@ -239,3 +239,27 @@ def test_table_finalize(V, E, C, G):
     with pytest.raises(_lib.ArcvaeHipError):
         _lib.call("arcvae_table_finalize", _lib.ptr(d["dT"]), _lib.ptr(d["Wx0"]), E - 1, _lib.ptr(d["emb"]),
                   _lib.ptr(d["dEmb"]), _lib.ptr(d["dWx0"]), _lib.ptr(d["db0"]), V, E, G, _lib.stream_ptr())
+
+
+def test_copy_buffers_one_launch():
+    """arcvae_copy_buffers: several small device-to-device copies in one launch (a step's inputs), every size and
+    alignment: 16-byte vector path, byte tails, unaligned views, an empty buffer."""
+    import ctypes as C
+    from arcvae_hip import _lib
+    rs = np.random.RandomState(5)
+    sizes = [64 * 128 * 4, 256, 64 * 128 * 4 + 4, 129, 0, 7, 4096 + 3]
+    srcs = [torch.tensor(rs.randint(0, 256, size=n + 32).astype(np.uint8), device="cuda") for n in sizes]
+    dsts = [torch.full((n + 32,), 255, dtype=torch.uint8, device="cuda") for n in sizes]
+    offs = [0, 0, 4, 1, 0, 3, 16]                                  # some views start off the 16-byte grid
+    sv = [s[o:o + n] for s, o, n in zip(srcs, offs, sizes)]
+    dv = [d[o:o + n] for d, o, n in zip(dsts, offs, sizes)]
+    keep = [(a, b) for a, b in zip(sv, dv) if a.numel() > 0]       # a null pointer (empty view) is an argument error
+    src, _k1 = _lib.ptr_array([a for a, _ in keep])
+    dst, _k2 = _lib.ptr_array([b for _, b in keep])
+    nb = (C.c_long * len(keep))(*[a.numel() for a, _ in keep])
+    _lib.call("arcvae_copy_buffers", src, dst, nb, len(keep), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    for s, d, o, n in zip(srcs, dsts, offs, sizes):
+        got = d.cpu().numpy()
+        assert np.array_equal(got[o:o + n], s.cpu().numpy()[o:o + n])
+        assert (got[:o] == 255).all() and (got[o + n:] == 255).all()      # nothing outside the range was touched
