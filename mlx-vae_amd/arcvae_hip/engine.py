@@ -276,15 +276,17 @@ class Gates:
     Words (one 128-B line each):  P main's signal count (exactly STRIDE per step), Q aux's (1 per step),
     R completions of aux + side (2 per step: main's join before the optimizer step), D decoder segments finished by side
     (1 per step: the data-parallel step reduces the decoder's gradients early), NS / NA / NM steps finished by
-    side / aux / main (the waiter's own ticket counter), ERR expired gates, PROBE self-test.
+    side / aux / main (the waiter's own ticket counter), ERR expired gates, PROBE self-test, H "the BPTT sweep has started"
+    (1 per step, raised by the sweep's first launch: the heads' dcomb chain in front of it is complete, so their
+    parameter gradients may be formed -- on aux, while the first chunk is still being swept and aux has nothing else).
     """
     STRIDE = 8
     LONG, SHORT = 16_000_000, 3_000    # polls (~1.5 us each): ~25 s before a gate gives up (a first RCCL collective
                                        # or a peer still capturing its graphs may hold main up for seconds); ~4 ms probe
-    P, Q, NS, NA, ERR, PROBE, R, NM, D = range(9)
+    P, Q, NS, NA, ERR, PROBE, R, NM, D, H = range(10)
 
     def __init__(self, device):
-        self.mem = torch.zeros(9 * 32, dtype=torch.int32, device=device)
+        self.mem = torch.zeros(10 * 32, dtype=torch.int32, device=device)
         self._probed: Dict[Tuple[int, int], bool] = {}
 
     def word(self, i: int) -> C.c_void_p:
@@ -594,7 +596,7 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             prologue()
         plan.heads(1)
         for c, (s0, s1, _t_lo, _t_hi, _first, _last) in enumerate(plan.chunks):
-            plan.sweep(s0, s1, g.word(g.P) if c > 0 else None, c)
+            plan.sweep(s0, s1, g.word(g.P) if c > 0 else g.word(g.H), c)   # chunk 0's first launch: "the sweep has started"
         g.signal(g.P, g.STRIDE - nc)
         if own_tables:
             _s0, _s1, t_lo_l, t_hi_l, _f, _l = plan.chunks[-1]
@@ -605,8 +607,17 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
         after_first()
     for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
         def aux_seg(c=c, t_lo=t_lo, t_hi=t_hi, first=first, last=last):
+            # ARCVAE_HEADS_EARLY=1 (opt-in): form the heads' parameter gradients at the sweep's START (gate word H) instead of
+            # behind chunk 0.  It paid while they were eight launches that dribbled in front of chunk 0's GEMMs (1.024 ->
+            # 1.017 ms at bs 64; but 1.78 -> 1.96 at bs 128); as ONE launch (heads_wgrad_kernel: 1.025 -> 1.006 ms) the
+            # two orders measure the same at bs 64 and the old one is ahead at bs 128 (1.765 vs 1.795), so it stays.
+            heads_early = os.environ.get("ARCVAE_HEADS_EARLY", "0") != "0"
+            if c == 0 and heads_early:
+                # the dcomb chain in front of the sweep is complete once the sweep has started
+                g.wait(g.H, g.NA, 1, 1)
+                plan.heads(2)
             g.wait(g.P, g.NA, g.STRIDE, g.STRIDE if last else 2 + c, advance=last)
-            if c == 0:
+            if c == 0 and not heads_early:
                 plan.heads(2)
             plan.wgrad(t_lo, t_hi, first, last,
                        8 if wx_on_side else (1 if (table_on_side or (last and tail_on_side)) else 3))

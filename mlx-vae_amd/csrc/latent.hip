@@ -402,6 +402,78 @@ extern "C" int arcvae_loss_finalize(const float* stats, float* scalars, int Z, i
 //   phase 1: dcomb [B,2H] = dmu_raw . Wmu + (dlv_raw . Wlv * (1 - lh^2)) . Wlh ; leaves dlh = d(pre-tanh) in ws
 //            (dcomb's first H columns are d/d(hT), consumed by arcvae_enc_lstm_backward with ld = 2H)
 //   phase 2: parameter gradients ("+=") from dmu_raw, dlv_raw, dlh, dcomb  -- any stream, after phase 1
+
+// ---- the heads' parameter gradients in ONE launch -----------------------------------------------------------------
+// dWmu += dmu_raw^T . comb, dWlv += dlv_raw^T . lh, dWlh += dlh^T . comb, dWc += dcr^T . cond and the four bias gradients
+// (= the column sums of the four left operands) were four GEMM launches + four column-sum launches of K = B <= a few
+// hundred: launch-bound work that runs on aux beside the persistent BPTT sweep, where every small dispatch waits for CU
+// resources -- the eight of them dribbled over ~180 us, sat in front of the first chunk's weight-gradient GEMMs and made
+// aux, not the chain, end the step (profiles/r02_tail_timeline.txt).  Here: 64 x 64 output tiles, K staged 16 rows at a
+// time in LDS, 4 x 4 outputs per thread as a k-ordered fmaf chain (the order of the f32 MFMA kernels it replaces); a
+// problem's first column of tiles also sums its left operand over k (the bias gradient).  Every output has one owner:
+// plain "+=", no atomics.
+namespace {
+struct HeadsWg {
+    const float* A[4];   // [K, M] (lda): dmu_raw, dlv_raw, dlh, dcomb + H
+    const float* B[4];   // [K, N] (ldb): comb, lh, comb, cond
+    float* C[4];         // [M, N] (ldc), +=
+    float* bias[4];      // [M], += column sums of A
+    int M[4], N[4], lda[4], ldb[4], ldc[4];
+    int tile0[5];        // first tile of problem i in blockIdx.x; tile0[4] = total
+    int K;
+};
+__global__ __launch_bounds__(256) void heads_wgrad_kernel(HeadsWg g) {
+    __shared__ __attribute__((aligned(16))) float As[16][64];
+    __shared__ __attribute__((aligned(16))) float Bs[16][64];
+    int pi = 0;
+    while (pi < 3 && (int)blockIdx.x >= g.tile0[pi + 1]) ++pi;
+    const int t = blockIdx.x - g.tile0[pi];
+    const int M = g.M[pi], N = g.N[pi], ntn = N > 0 ? (N + 63) >> 6 : 1;
+    const int m0 = (t / ntn) * 64, n0 = (t % ntn) * 64;
+    const float* __restrict__ A = g.A[pi];
+    const float* __restrict__ Bm = g.B[pi];
+    const int lda = g.lda[pi], ldb = g.ldb[pi];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;          // outputs: rows m0 + 4 ty + i, columns n0 + 4 tx + j
+    float acc[4][4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, kk = idx >> 6, c = idx & 63;
+            const bool kin = k0 + kk < g.K;
+            As[kk][c] = (kin && m0 + c < M) ? A[(long)(k0 + kk) * lda + m0 + c] : 0.f;
+            Bs[kk][c] = (kin && n0 + c < N) ? Bm[(long)(k0 + kk) * ldb + n0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[kk][4 * ty]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[kk][4 * tx]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bsum[i] += a[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * ty + i;
+        if (m >= M) continue;
+        float* c = g.C[pi] + (long)m * g.ldc[pi] + n0 + 4 * tx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + 4 * tx + j < N) c[j] += acc[i][j];
+        if (n0 == 0 && tx == 0 && g.bias[pi]) g.bias[pi][m] += bsum[i];
+    }
+}
+}  // namespace
+
 extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, const float* Wlh, const float* Wlv,
                                          const float* comb, const float* lh, const float* dmu_raw,
                                          const float* dlv_raw, float* dlh, float* dcomb, float* dWc, float* dbc,
@@ -432,6 +504,28 @@ extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, co
             return rc;
         }
         if ((rc = arcvae_gemm_f32(0, 0, B, H2, H2, dlh, H2, Wlh, H2, dcomb, H2, nullptr, ACC, stream))) return rc;
+    }
+    if ((phase == 0 || phase == 2) && arcvae_env_int("ARCVAE_HEADS_WGRAD_FUSED", 1) != 0) {   // one launch (heads_wgrad_kernel)
+        HeadsWg g;
+        const float* As_[4] = {dmu_raw, dlv_raw, dlh, dcomb + H};
+        const float* Bs_[4] = {comb, lh, comb, cond};
+        float* Cs_[4] = {dWmu, dWlv, dWlh, dWc};
+        float* bs_[4] = {dbmu, dblv, dblh, dbc};
+        const int Ms[4] = {Z, Z, H2, H}, Ns[4] = {H2, H2, H2, C}, la[4] = {Z, Z, H2, H2}, lb[4] = {H2, H2, H2, C > 0 ? C : 1},
+                  lc[4] = {H2, H2, H2, C > 0 ? C : 1};
+        int tiles = 0;
+        for (int i = 0; i < 4; ++i) {
+            g.A[i] = As_[i]; g.B[i] = Bs_[i]; g.C[i] = Cs_[i]; g.bias[i] = bs_[i];
+            g.M[i] = Ms[i]; g.N[i] = Ns[i]; g.lda[i] = la[i]; g.ldb[i] = lb[i]; g.ldc[i] = lc[i];
+            g.tile0[i] = tiles;
+            // condition_fc with C == 0 has no weight, but its bias gradient (column sums of dcomb[:, H:]) still exists:
+            // one column of (empty) tiles
+            tiles += ceil_div(Ms[i], 64) * (Ns[i] > 0 ? ceil_div(Ns[i], 64) : 1);
+        }
+        g.tile0[4] = tiles;
+        g.K = B;
+        hipLaunchKernelGGL(heads_wgrad_kernel, dim3(tiles), dim3(256), 0, stream, g);
+        return arcvae_launch_status();
     }
     if (phase == 0 || phase == 2) {
         if ((rc = arcvae_gemm_f32(1, 0, Z, H2, B, dmu_raw, Z, comb, H2, dWmu, H2, nullptr, ACC, stream))) return rc;

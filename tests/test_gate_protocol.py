@@ -50,13 +50,13 @@ class _Plan:
         self.chunks = E.EncoderBackwardPlan.chunk_schedule(T, L, fractions)
 
     def heads(self, phase):
-        pass
+        self.g.note("heads", phase)             # 1: the dcomb chain (main, in front of the sweep); 2: the heads' parameter gradients
 
     def sweep(self, s0, s1, start_signal=None, chunk_index=0):
         c = [i for i, ch in enumerate(self.chunks) if ch[0] == s0][0]
         if start_signal is not None:            # raised by the first launch of the chunk when it starts
-            assert start_signal == ("word", E.Gates.P)
-            self.g.note("signal", E.Gates.P, 1)
+            assert start_signal == ("word", E.Gates.P if c > 0 else E.Gates.H)   # chunk 0: "the BPTT sweep has started"
+            self.g.note("signal", start_signal[1], 1)
         self.g.note("sweep_done", c)
 
     def wgrad(self, t_lo, t_hi, first, last, parts=3, table=None):
@@ -109,6 +109,7 @@ def _replay(ops, streams, steps):
     prog = {s: ops[s] * steps for s in streams}
     per = {s: len(ops[s]) for s in streams}
     sweeps_done = set()                          # (step, chunk)
+    heads1_done = set()                          # steps whose dcomb chain (heads phase 1) has run
     advanced = {}
     reduced_early = []
     nc_last = max([op[1] for op in ops[main] if op[0] == "sweep_done"], default=0)
@@ -133,6 +134,11 @@ def _replay(ops, streams, steps):
                     flags[op[1]] = flags.get(op[1], 0) + op[2]
                 elif op[0] == "sweep_done":
                     sweeps_done.add((step, op[1]))
+                elif op[0] == "heads":
+                    if op[1] == 1:
+                        heads1_done.add(step)
+                    else:                        # the heads' parameter gradients read what the dcomb chain of THIS step wrote
+                        assert step in heads1_done, f"{s.name}: heads' parameter gradients before the dcomb chain (step {step})"
                 elif op[0] == "wgrad":
                     assert (step, op[1]) in sweeps_done, f"{s.name}: gradients of chunk {op[1]} before its sweep (step {step})"
                 elif op[0] == "dec_reduce":          # the decoder's bucket is reduced beside the sweep: before its LAST chunk is done
@@ -144,7 +150,8 @@ def _replay(ops, streams, steps):
     return flags, advanced
 
 
-@pytest.mark.parametrize("env", [{}, {"ARCVAE_TABLE_ON_SIDE": "0"}, {"ARCVAE_WX_ON_SIDE": "1"}, {"ARCVAE_WX_ON_SIDE": "0"}])
+@pytest.mark.parametrize("env", [{}, {"ARCVAE_TABLE_ON_SIDE": "0"}, {"ARCVAE_WX_ON_SIDE": "1"}, {"ARCVAE_WX_ON_SIDE": "0"},
+                                 {"ARCVAE_HEADS_EARLY": "1"}])
 @pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("T,L,fractions", [(128, 2, (0.3, 0.6, 0.85, 1.0)), (128, 2, (0.63, 1.0)), (12, 2, (0.63, 1.0)),
                                            (40, 4, (0.1, 0.2, 0.3, 0.5, 0.7, 0.9, 1.0)), (9, 1, (0.5, 1.0)), (5, 3, (0.3, 0.6, 0.85, 1.0))])
