@@ -133,7 +133,9 @@ int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0,
 /* cond .. stats (optional, all or none): also comb[:, H:2H] = condition_fc(cond) (models/encoder.py:109-112) and
  * stats[0..n_stats) = 0, for arcvae_enc_heads_forward(comb_ready = 1).  onehot_ws (optional, [T*B, roundup(V,4)]): the
  * one-hot token rows of arcvae_enc_lstm_wgrad (called with parts bit 5 then). */
-int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, unsigned* sync_ws, int n_sync,
+int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, float* zero2_f32 /* optional second
+                        zero fill: the token-table workspaces of arcvae_enc_lstm_wgrad (parts bit 8 then) */, long n_zero2,
+                        unsigned* sync_ws, int n_sync,
                         const float* cond, const float* Wc, const float* bc, float* comb, float* stats, int n_stats,
                         float* onehot_ws, int V, int B, int T, int H, int C, arcvae_stream_t stream);
 int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L);
@@ -172,7 +174,8 @@ int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* W
  * that may run on different streams: bit 0 = per-layer GEMMs and bias sums (= bits 2 | 3), bit 1 = token-table path,
  * bit 2 = dWx_l (l >= 1) and bias sums only, bit 3 = dWh_l only; bit 4 = exact-f32 tile GEMMs instead of the split-bf16
  * kernel; bit 5 = onehot_ws was written by arcvae_enc_prologue; bit 6 = the split-bf16 kernel's 128-row tile (the range
- * runs behind the sweep, no sweep block is resident); bit 7 = throughput mode (one bf16 product per GEMM step instead of
+ * runs behind the sweep, no sweep block is resident); bit 8 = dtable_ws was zeroed ahead of the call (arcvae_enc_prologue:
+ * the zero-fill launch in front of a `first` range is skipped); bit 7 = throughput mode (one bf16 product per GEMM step instead of
  * the six of the split form: not a parity path).  The token-table path is linear in dtable_ws, so a
  * time range may be given its own workspace and both `first` and `last` (zero, accumulate, fold) on any stream. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,

@@ -120,8 +120,10 @@ class Workspace:
             self.dcs = torch.empty(L, RS, B, H, **f32)
             self.dxs = torch.empty(L, RS, B, H, **f32)
             self.wT = torch.empty(2 * L - 1, H, G, **f32)
-            self.dtable0 = torch.empty(V, G, **f32)
-            self.dtable1 = torch.empty(V, G, **f32)           # the last chunk's token table, folded by the main stream itself
+            self.dtables = torch.zeros(2, V, G, **f32)        # both token tables: one zero fill (arcvae_enc_prologue)
+            self.dtable0 = self.dtables[0]
+            self.dtable1 = self.dtables[1]                    # the last chunk's token table, folded by the main stream itself
+            self.tables_zeroed = False                        # this step's prologue has zeroed them (persistent forward path)
             self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)
             if H == 256 and L <= 2 and B <= 256:  # partial sums in flight of the reduce-scatter BPTT sweep (12.6 MB per
                 rg = 1 if B <= 64 else (2 if B <= 128 else 4)   # group of 8 rows per XCD)
@@ -187,8 +189,10 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         # The prologue also writes the condition half of the heads' input and clears `stats`; the sweep's last tick stores
         # h_{T-1} of the top layer into the other half: the heads start without a build launch.
         grad = enc.grad if zero_grad else None
+        tabs = ws.dtables if (zero_grad and hasattr(ws, "dtables")) else None   # the token tables of the step's two chunks
+        ws.tables_zeroed = tabs is not None
         call("arcvae_enc_prologue", ptr(ws.x), ptr(ws.x_tb), ptr(grad), C.c_long(grad.numel() if grad is not None else 0),
-             ptr(ws.psync), 272, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
+             ptr(tabs), C.c_long(tabs.numel() if tabs is not None else 0), ptr(ws.psync), 272, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
              ptr(ws.comb), ptr(ws.stats), 2 * d.Z + 4, ptr(ws.onehot) if (zero_grad and hasattr(ws, "onehot")) else C.c_void_p(0),
              d.V, B, T, d.H, d.C, s)
         comb_ready = 1
@@ -588,6 +592,12 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     # forward path).  ARCVAE_TABLE_ON_MAIN=0: round 1's accumulate-on-side form.
     own_tables = table_on_side and _tables_on_main(plan, ws)
 
+    def pre_zeroed() -> int:
+        # parts bit 8: this step's prologue has zeroed both token tables and each is used once (two chunks): no zero-fill
+        # launch in front of the one-hot GEMM -- 5 us of main's exposed tail, and on side a dispatch that waited ~40 us
+        # for CU resources beside the sweep (profiles/r02_tail_timeline.txt)
+        return 256 if (nc == 2 and ws is not None and getattr(ws, "tables_zeroed", False)) else 0
+
     def main_seg():
         # the whole critical chain of the backward as ONE captured segment: the "chunk c done" signal is raised by
         # the first launch of chunk c+1 when it starts (no launch of its own, no segment seam); only the last
@@ -600,7 +610,7 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
         g.signal(g.P, g.STRIDE - nc)
         if own_tables:
             _s0, _s1, t_lo_l, t_hi_l, _f, _l = plan.chunks[-1]
-            plan.wgrad(t_lo_l, t_hi_l, True, True, 2 | 32, table=getattr(ws, "dtable1", None))
+            plan.wgrad(t_lo_l, t_hi_l, True, True, 2 | 32 | pre_zeroed(), table=getattr(ws, "dtable1", None))
 
     run("main", main_seg, main)
     if after_first:
@@ -633,7 +643,7 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
                 g.wait(g.Q, g.NS, 1, 1)
                 g.wait(g.P, g.NS, g.STRIDE, g.STRIDE, advance=True)
             if own_tables:   # this chunk's own table (not the last chunk's: main forms that one)
-                plan.wgrad(t_lo, t_hi, True, True, ((4 if wx_on_side else 0) | (0 if last else 2)) | 32)
+                plan.wgrad(t_lo, t_hi, True, True, ((4 if wx_on_side else 0) | (0 if last else 2)) | 32 | pre_zeroed())
             else:
                 plan.wgrad(t_lo, t_hi, first, last, 6 if wx_on_side else 2)
             if last:

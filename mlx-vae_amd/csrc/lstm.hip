@@ -2553,6 +2553,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
     const bool do_layers = do_wx || do_wh;
     const int Vp = (V + 3) & ~3;
     if (do_table && first) {
+        if (!(parts & 256))   // bit 8: the table workspace was zeroed ahead of the call (arcvae_enc_prologue)
         if (arcvae_zero(dtable_ws, V, G, G, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
         const long n = (long)TB * Vp;
         if (!(parts & 32))   // bit 5: the one-hot rows were written by arcvae_enc_prologue

@@ -62,7 +62,7 @@ class _Plan:
     def wgrad(self, t_lo, t_hi, first, last, parts=3, table=None):
         c = [i for i, ch in enumerate(self.chunks) if ch[2] == t_lo and ch[3] == t_hi][0]
         if parts & 15:
-            self.g.note("wgrad", c, parts & 15)     # bits 4, 5 choose kernels / workspaces, not pieces
+            self.g.note("wgrad", c, parts & 15)     # bits 4, 5, 8 choose kernels / workspaces / the zero fill, not pieces
 
 
 def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
