@@ -110,7 +110,8 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
 /* The same forward sweep as ONE persistent launch for the latency regime (H = 128, 256 or 384, L <= 4, B <= 256, weight
  * slices within LDS; arcvae_enc_lstm_persistent_ok says whether a shape qualifies): batch rows partitioned over the 8
  * XCDs, weights stationary in LDS, one flag-line barrier per XCD and tick.  No k-chunk-major h
- * copy is written.  sync_ws: 512 u32 of scratch; sync_ws[500] != 0 afterwards = a block gave up waiting (sticky).
+ * copy is written.  sync_ws: 1024 u32 of scratch (forward: words [0, 272); the BPTT entry points: [512, 848); [500] = the
+ * error word of both); sync_ws[500] != 0 afterwards = a block gave up waiting (sticky).
  * start_signal (optional): += 1 when the sweep starts.  The BPTT counterpart covers ticks [s_begin, s_end) of
  * arcvae_enc_lstm_backward's schedule per launch (L <= 2, ceil(B/8) * H/32 <= 64); a sweep uses it for all its
  * chunks or for none (no k-chunk-major dG copy is written).  chunk_index: 0 for the launch with s_begin == 0 (it
@@ -135,7 +136,8 @@ int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0,
  * one-hot token rows of arcvae_enc_lstm_wgrad (called with parts bit 5 then). */
 int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, float* zero2_f32 /* optional second
                         zero fill: the token-table workspaces of arcvae_enc_lstm_wgrad (parts bit 8 then) */, long n_zero2,
-                        unsigned* sync_ws, int n_sync,
+                        unsigned* sync_ws, int n_sync, int sync_keep /* word index left alone, or -1: the sweeps' sticky error
+                        word 500 when n_sync covers it -- 848 re-arms the forward AND the BPTT sweep of the step */,
                         const float* cond, const float* Wc, const float* bc, float* comb, float* stats, int n_stats,
                         float* onehot_ws, int V, int B, int T, int H, int C, arcvae_stream_t stream);
 int arcvae_enc_lstm_bwd_persistent_ok(int B, int T, int H, int L);
@@ -152,7 +154,8 @@ int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* 
                                            const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
                                            float* dxs, float* part_ws, unsigned* sync_ws, unsigned* start_signal, int B,
                                            int T, int H, int L, int s_begin, int s_end, int chunk_index,
-                                           int flags /* ARCVAE_PERSIST_BF16 or 0 */, unsigned long long* trace,
+                                           int flags /* bit 0: sync_ws was re-armed ahead of the step (arcvae_enc_prologue with
+                                           n_sync >= 848); bit 1: ARCVAE_PERSIST_BF16 */, unsigned long long* trace,
                                            arcvae_stream_t stream);
 /* The reduce-scatter sweep with the stack's weight gradients formed INSIDE the kernel: replaces
  * arcvae_enc_lstm_backward_persistent_rs + the per-layer GEMMs / bias sums / token segment-sum of arcvae_enc_lstm_wgrad

@@ -93,7 +93,9 @@ class Workspace:
         self.logvar = torch.empty(B, Z, **f32)
         self.z = torch.empty(B, Z, **f32)
         self.stats = torch.zeros(2 * Z + 4, **f32)
-        self.psync = torch.zeros(512, **i32)     # scratch of the persistent sweeps (flags, role counters; [500] = error)
+        self.psync = torch.zeros(1024, **i32)    # scratch of the persistent sweeps: forward flags / role counters at [0, 272), the
+        #                                          BPTT sweeps' at [512, 848), [500] = the sticky error word of both
+        self.bptt_rearmed = False                # the prologue of this step's forward has zeroed the BPTT sweep's words too
         # optional diagnostic stamps of the sweep launches / ticks (StepEngine.enable_trace), passed per call
         self.trace_fwd: Optional[torch.Tensor] = None
         self.trace_bwd: Optional[torch.Tensor] = None
@@ -191,8 +193,9 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         grad = enc.grad if zero_grad else None
         tabs = ws.dtables if (zero_grad and hasattr(ws, "dtables")) else None   # the token tables of the step's two chunks
         ws.tables_zeroed = tabs is not None
+        ws.bptt_rearmed = True                   # consumed by the next EncoderBackwardPlan.sweep(chunk 0)
         call("arcvae_enc_prologue", ptr(ws.x), ptr(ws.x_tb), ptr(grad), C.c_long(grad.numel() if grad is not None else 0),
-             ptr(tabs), C.c_long(tabs.numel() if tabs is not None else 0), ptr(ws.psync), 272, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
+             ptr(tabs), C.c_long(tabs.numel() if tabs is not None else 0), ptr(ws.psync), 848, 500, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
              ptr(ws.comb), ptr(ws.stats), 2 * d.Z + 4, ptr(ws.onehot) if (zero_grad and hasattr(ws, "onehot")) else C.c_void_p(0),
              d.V, B, T, d.H, d.C, s)
         comb_ready = 1
@@ -433,6 +436,11 @@ class EncoderBackwardPlan:
         # d/d(hT) = dcomb[:, :H] (row stride 2H)
         ws, d = self.ws, self.d
         sig = start_signal if start_signal is not None else C.c_void_p(0)
+        # flags bit 0 of the reduce-scatter entry point: its sync words are armed (the prologue of the forward that ran
+        # last zeroed them and no BPTT sweep has used them since) -- no zero-fill launch between the seam and the sweep
+        rearmed = 1 if (chunk_index == 0 and getattr(ws, "bptt_rearmed", False)) else 0
+        if chunk_index == 0:
+            ws.bptt_rearmed = False
         if self.fused:
             # default shape: the reduce-scatter sweep with the weight gradients formed inside it
             enc = self.enc
@@ -446,7 +454,7 @@ class EncoderBackwardPlan:
             # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
             call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
                  ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), ptr(ws.psync), sig,
-                 ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, _lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0,
+                 ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0) | rearmed,
                  ptr(ws.trace_bwd), stream_ptr())
             return
         if _lib.load().arcvae_enc_lstm_bwd_persistent_ok(ws.B, ws.T, d.H, d.L) == 1:

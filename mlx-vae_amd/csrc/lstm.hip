@@ -931,7 +931,10 @@ inline bool choose_step2(int B) {
 // exactly 32).  Every spin is bounded; a block that gives up raises sync[PS_ERR] and all blocks drain.
 // Shapes: H = 128 * NT (NT = 1..3), L <= 4, ceil(B / 8) <= 16 rows per XCD, weight slices within LDS.
 constexpr int PS_FLAGS = 0, PS_CNT = 256, PS_WORDS = 272;   // re-armed (zeroed) before every sweep: flags, role counters
-constexpr int PS_ERR = 500;                                  // sticky error word, outside the re-armed range (buffer: 512 words)
+constexpr int PS_ERR = 500;                                  // sticky error word, outside the re-armed ranges
+constexpr int PS_BWD = 512;                                  // the BPTT sweeps' flags / role counters live at sync_ws + PS_BWD (their own
+                                                             // words: both sweeps of a step can be re-armed by ONE zero fill ahead of the
+                                                             // forward, arcvae_enc_prologue); the error word is shared (buffer: 1024 words)
 struct PersistArgs {
     const int32_t* x_tb;
     const float* table0;
@@ -1356,6 +1359,7 @@ struct PersistBwdArgs {
     float* dcs;               // [L][RS][B][H] ring
     float* dxs;               // [L][RS][B][H] ring
     unsigned* sync;           // PS_WORDS words; flags hold the global tick index, role counters per chunk launch
+    unsigned* err;            // the sticky error word (sync_ws + PS_ERR, shared with the forward sweep)
     unsigned* start_signal;
     unsigned long long* trace;
     int B, T, H, RX, RS, ld_dh_top, s_begin, s_end, cnt_off, prio;
@@ -1389,7 +1393,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
     __syncthreads();
     const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);   // wave-uniform (SGPRs)
     if (xcc >= 8 || role >= 32) {
-        if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
+        if (tid == 0) atomicAdd(a.err, 1u);
         return;
     }
     const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
@@ -1455,8 +1459,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
                     const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                    : (unsigned)s;
                     if (__all((int)(v - (unsigned)s) >= 0)) break;
-                    if (++spins > 4000000u || __hip_atomic_load(a.sync + PS_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        if (lane == 0) { atomicAdd(a.sync + PS_ERR, 1u); s_ok = 0; }
+                    if (++spins > 4000000u || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        if (lane == 0) { atomicAdd(a.err, 1u); s_ok = 0; }
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
@@ -1641,7 +1645,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
     __syncthreads();
     const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);   // wave-uniform (SGPRs)
     if (xcc >= 8 || role >= 32) {
-        if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
+        if (tid == 0) atomicAdd(a.err, 1u);
         return;
     }
     const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
@@ -1921,8 +1925,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                 const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                : (unsigned)(s + 1);
                 if (__all((int)(v - (unsigned)(s + 1)) >= 0)) break;
-                if (++spins > 4000000u || __hip_atomic_load(a.sync + PS_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    if (lane == 0) { atomicAdd(a.sync + PS_ERR, 1u); s_ok = 0; }
+                if (++spins > 4000000u || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) { atomicAdd(a.err, 1u); s_ok = 0; }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -2266,12 +2270,12 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
     // role counters: a fresh set of 8 words per chunk launch of a sweep (all zeroed by chunk 0)
     if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
     if (chunk_index == 0) {
-        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws + PS_BWD), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
         if (rc != ARCVAE_OK) return rc;
     }
     PersistBwdArgs a;
     a.wT = wT; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
-    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace;
+    a.sync = sync_ws + PS_BWD; a.err = sync_ws + PS_ERR; a.start_signal = start_signal; a.trace = trace;
     a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
     a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);   // chunk 0: words 256..263, then 272..
@@ -2315,14 +2319,14 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     const int S = T + 2 * (L - 1);
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
-    if (chunk_index == 0) {
-        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+    if (chunk_index == 0 && !(flags & 1)) {   // flags bit 0: the words were zeroed ahead of the step (arcvae_enc_prologue)
+        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws + PS_BWD), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
         if (rc != ARCVAE_OK) return rc;
     }
     PersistRsArgs ar;
     PersistBwdArgs& a = ar.b;
     a.wT = nullptr; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
-    a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace;
+    a.sync = sync_ws + PS_BWD; a.err = sync_ws + PS_ERR; a.start_signal = start_signal; a.trace = trace;
     a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
     a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);

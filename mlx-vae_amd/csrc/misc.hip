@@ -422,7 +422,7 @@ extern "C" int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw,
 // took ~70 us on uncoalesced weight rows) -----------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __restrict__ x_bt, int32_t* x_tb, int B, int T,
-                                                           float4* zero, long nz4, float4* zero2, long nz4b, unsigned* sync, int nsync,
+                                                           float4* zero, long nz4, float4* zero2, long nz4b, unsigned* sync, int nsync, int keep,
                                                            const float* __restrict__ cond, const float* __restrict__ Wc,
                                                            const float* __restrict__ bc, float* comb, float* stats,
                                                            int nstats, int H, int C, float* onehot, int V, int Vp) {
@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __rest
         const int t = (int)(i / B), bb = (int)(i % B);
         x_tb[i] = x_bt[(long)bb * T + t];
     }
-    for (long i = gt; i < nsync; i += gs) sync[i] = 0u;
+    for (long i = gt; i < nsync; i += gs)
+        if (i != keep) sync[i] = 0u;          // (the sweeps' sticky error word stays)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long i = gt; i < nz4; i += gs) zero[i] = z;
     for (long i = gt; i < nz4b; i += gs) zero2[i] = z;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(256) void enc_prologue_kernel(const int32_t* __rest
 // need no build_comb launch (arcvae_enc_heads_forward(comb_ready = 1)).  onehot_ws (optional, [T*B, roundup(V,4)]): the
 // one-hot token rows of arcvae_enc_lstm_wgrad (then called with parts bit 5).
 extern "C" int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* zero_f32, long n_zero, float* zero2_f32,
-                                   long n_zero2, unsigned* sync_ws, int n_sync, const float* cond, const float* Wc, const float* bc, float* comb,
+                                   long n_zero2, unsigned* sync_ws, int n_sync, int sync_keep, const float* cond, const float* Wc, const float* bc, float* comb,
                                    float* stats, int n_stats, float* onehot_ws, int V, int B, int T, int H, int C,
                                    hipStream_t stream) {
     if (!x_bt || !x_tb || B <= 0 || T <= 0) return ARCVAE_ERR_ARG;
@@ -475,7 +476,7 @@ extern "C" int arcvae_enc_prologue(const int32_t* x_bt, int32_t* x_tb, float* ze
     if (n_sync < 0 || (n_sync > 0 && !sync_ws)) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(enc_prologue_kernel, dim3(256), dim3(256), 0, stream, x_bt, x_tb, B, T,
                        reinterpret_cast<float4*>(zero_f32), zero_f32 ? n_zero / 4 : 0L, reinterpret_cast<float4*>(zero2_f32),
-                       zero2_f32 ? n_zero2 / 4 : 0L, sync_ws, n_sync, cond, Wc, bc, comb,
+                       zero2_f32 ? n_zero2 / 4 : 0L, sync_ws, n_sync, sync_keep, cond, Wc, bc, comb,
                        stats, n_stats, H, C, onehot_ws, V, (V + 3) & ~3);
     return arcvae_launch_status();
 }
