@@ -453,6 +453,9 @@ struct SplitTN {
     const float* A;   // [K, M]
     const float* B;   // [K, N]
     float* C;         // [M, N], +=
+    float* colsum;    // optional [M]: += the column sums of A over K (the bias gradient that goes with a weight-gradient GEMM:
+                      // the first column of tiles sums the values it loads anyway -- a separate column-sum launch beside the
+                      // persistent sweep waited ~60 us for CU resources, profiles/r02_tail_timeline.txt)
     int M, N, K, lda, ldb, ldc, kchunk;
 };
 #define ARCVAE_SPLIT_GROUP_MAX 8
@@ -496,6 +499,10 @@ __device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, co
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     float ra[2][8][MI];
     float rb[2][8][NJ];
+    const bool do_cs = p.colsum != nullptr && bx == 0;   // block-uniform
+    float csum[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) csum[i] = 0.f;
 #define SPLIT_LOAD(BUF, K0)                                                                                       \
     _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                                            \
         const int k = (K0) + 8 * h + kk;                                                                          \
@@ -517,6 +524,10 @@ __device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, co
     // one K = 16 step from buffer BUF: split into bf16 pieces, refill the buffer two steps ahead, 6 products per tile
 #define SPLIT_STEP(BUF, K0)                                                                                       \
     {                                                                                                             \
+        if (do_cs) {                                                                                              \
+            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk)                                                      \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) csum[i] += ra[BUF][kk][i];                             \
+        }                                                                                                         \
         u32x4_g ah[MI], amid[MI], al[MI], bh[NJ], bm[NJ], bl[NJ];                                                 \
         _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                           \
             unsigned x, y = 0, z = 0;                                                                             \
@@ -559,6 +570,13 @@ __device__ __forceinline__ void split_tn_body(const SplitTN& p, const int bx, co
     }
 #undef SPLIT_STEP
 #undef SPLIT_LOAD
+    if (do_cs) {   // my columns am .. am + MI - 1: the two k-halves of the wave, then one atomic per wave and column
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float v = csum[i] + __shfl_xor(csum[i], 32);
+            if (h == 0 && aok) atomicAdd(p.colsum + am + i, v);
+        }
+    }
     // ---- sum the four waves' accumulators: red [2 regions][TT tiles][16][64 lanes]
     const int reg = wave >> 1;
     if (wave & 1) {
@@ -833,7 +851,7 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     if (transA && !transB && (flags & ARCVAE_GEMM_ACCUMULATE) && (flags & ARCVAE_GEMM_SPLITK) && !bias && p.act == 0 &&
         !(flags & (ARCVAE_GEMM_TILE64 | ARCVAE_GEMM_TILE128)) && split_tn_ok(M, N, A, lda, B, ldb)) {
         SplitTN q;
-        q.A = A; q.B = B; q.C = C; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.kchunk = 0;
+        q.A = A; q.B = B; q.C = C; q.colsum = nullptr; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.kchunk = 0;
         return launch_split_tn_group(1, &q, (flags & ARCVAE_GEMM_TILE_WIDE) != 0, (flags & ARCVAE_GEMM_BF16) != 0, stream);
     }
     // throughput mode: bf16 operands, f32 accumulate (everything but the minibatch-sized products on the chain, which
@@ -933,10 +951,20 @@ int arcvae_gemm_skinny_pair(int transB, const int* M, const int* N, const int* K
 // C_i[M,N] += A_i^T . B_i for i < n, one launch: A_i stored [K_i, M] (lda), B_i stored [K_i, N] (ldb), all f32
 // atomics (split-K inside each problem).  Internal (ops.h); falls back to n single launches when the operands do
 // not allow the 16-byte path.
+// colsum (optional, per problem, entries may be null): colsum_i[M] += column sums of A_i over K_i -- inside the split kernel
+// where that runs, by arcvae_colsum_accum launches on every other path.
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
                                const float* const* B, int ldb, float* const* C, int ldc, int allow_split,
-                               hipStream_t stream) {
+                               float* const* colsum, hipStream_t stream) {
     if (n <= 0 || n > ARCVAE_GEMM_GROUP_MAX || M <= 0 || N <= 0) return ARCVAE_ERR_ARG;
+    auto colsums_by_launch = [&]() -> int {
+        for (int i = 0; colsum && i < n; ++i)
+            if (colsum[i] && K[i] > 0) {
+                const int rc = arcvae_colsum_accum(A[i], K[i], M, lda, colsum[i], 1.0f, stream);
+                if (rc) return rc;
+            }
+        return ARCVAE_OK;
+    };
     if ((allow_split & 4) && M >= 256 && N >= 256) {   // throughput mode, large outputs: one bf16 tile-kernel launch per problem
         for (int i = 0; i < n; ++i) {
             if (K[i] <= 0) continue;
@@ -944,7 +972,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
                                            ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_BF16, stream);
             if (rc) return rc;
         }
-        return ARCVAE_OK;
+        return colsums_by_launch();
     }
     if (allow_split) {   // bit 0 = split-bf16 kernel; bit 1 = its 128-row tile (no sweep resident); bit 2 = one bf16 product (throughput mode)
         bool ok = true;
@@ -952,7 +980,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
         if (ok) {
             SplitTN q[ARCVAE_SPLIT_GROUP_MAX];
             for (int i = 0; i < n; ++i) {
-                q[i].A = A[i]; q[i].B = B[i]; q[i].C = C[i]; q[i].M = M; q[i].N = N; q[i].K = K[i];
+                q[i].A = A[i]; q[i].B = B[i]; q[i].C = C[i]; q[i].colsum = colsum ? colsum[i] : nullptr; q[i].M = M; q[i].N = N; q[i].K = K[i];
                 q[i].lda = lda; q[i].ldb = ldb; q[i].ldc = ldc; q[i].kchunk = 0;
             }
             return launch_split_tn_group(n, q, (allow_split & 2) != 0, (allow_split & 4) != 0, stream);
@@ -967,7 +995,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
                                            ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK, stream);
             if (rc) return rc;
         }
-        return ARCVAE_OK;
+        return colsums_by_launch();
     }
     GemmGroup g;
     g.n = n;
@@ -991,7 +1019,8 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
     dim3 grid(ceil_div(N, 64), ceil_div(M, 64), ztot);
     const unsigned pad = arcvae_side_lds_pad(2 * BK * (64 + 64 + 2 * PAD) * sizeof(float));
     hipLaunchKernelGGL((gemm_tile_group_kernel<64, 64, false, false, 4, 4>), grid, dim3(256), pad, stream, g);
-    return arcvae_launch_status();
+    if (arcvae_launch_status() != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+    return colsums_by_launch();
 }
 
 // C_i[M,N] += A_i^T . B_i from octet-major bf16 operand copies (wgrad_octet_kernel), i < n <= 8, one launch.  Internal (ops.h).

@@ -2570,6 +2570,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
             const float* Ag[2 * ARCVAE_MAX_LAYERS];
             const float* Bg[2 * ARCVAE_MAX_LAYERS];
             float* Cg[2 * ARCVAE_MAX_LAYERS];
+            float* Sg[2 * ARCVAE_MAX_LAYERS];    // bias gradient that rides with the problem (dWx_l: dbias_l), or null
             int Kg[2 * ARCVAE_MAX_LAYERS];
             int n = 0;
             const int t1 = t_lo > 1 ? t_lo : 1;  // dWh pairs dG[t] with h[t-1]
@@ -2577,11 +2578,11 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                 const float* dGl = dG + l * lG;
                 if (do_wh && t_hi > t1) {
                     Ag[n] = dGl + (long)t1 * B * G; Bg[n] = hseq + l * lH + (long)(t1 - 1) * B * H;
-                    Cg[n] = dWh[l]; Kg[n] = (t_hi - t1) * B; ++n;
+                    Cg[n] = dWh[l]; Sg[n] = nullptr; Kg[n] = (t_hi - t1) * B; ++n;
                 }
                 if (do_wx && l > 0) {
                     Ag[n] = dGl + (long)t_lo * B * G; Bg[n] = hseq + (l - 1) * lH + (long)t_lo * B * H;
-                    Cg[n] = dWx[l]; Kg[n] = nt * B; ++n;
+                    Cg[n] = dWx[l]; Sg[n] = dbias[l]; Kg[n] = nt * B; ++n;   // same rows as the bias sum: colsum(dG_l[t_lo..t_hi))
                 }
             }
             if (b16 && h_oct && dG_oct && (B % 16) == 0) {
@@ -2596,15 +2597,13 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                     rc = arcvae_wgrad_octet_group(n - i < 8 ? n - i : 8, G, H, Kg + i, Ao + i, Bo + i, Cg + i, H, stream);
                     if (rc) return rc;
                 }
+                for (int i = 0; i < n; ++i)      // (the octet kernel has no bias-sum rider)
+                    if (Sg[i]) { rc = arcvae_colsum_accum(Ag[i], Kg[i], G, G, Sg[i], 1.0f, stream); if (rc) return rc; }
             } else
             for (int i = 0; i < n; i += 8) {
                 rc = arcvae_gemm_tn_group_accum(n - i < 8 ? n - i : 8, G, H, Kg + i, Ag + i, G, Bg + i, H, Cg + i, H,
-                                                exact_f32 ? 0 : (1 | (wide ? 2 : 0) | (b16 ? 4 : 0)), stream);
-                if (rc) return rc;
-            }
-            for (int l = 1; l < L && do_wx; ++l) {
-                rc = arcvae_colsum_accum(dG + l * lG + (long)t_lo * B * G, nt * B, G, G, dbias[l], 1.0f, stream);
-                if (rc) return rc;
+                                                exact_f32 ? 0 : (1 | (wide ? 2 : 0) | (b16 ? 4 : 0)), Sg + i, stream);
+                if (rc) return rc;       // (bias gradients dbias_l += colsum(dG_l): inside the split kernel, else by launch)
             }
         }
         if (do_table) {  // dTable0 += OneHot[rows]^T . dG_0[rows]   (see onehot_kernel)

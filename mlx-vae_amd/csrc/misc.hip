@@ -217,29 +217,34 @@ __global__ __launch_bounds__(256) void table_finalize_kernel(const float* __rest
         return;
     }
     bid -= nA;
-    if (bid < nB) {                                   // ---- dWx0: 16 gate rows (8 per half) x 128 e, K = V
-        const int et = bid % etiles, g0 = (bid / etiles) * 16;
-        const int e0 = et * 128, e = e0 + e_l;
+    if (bid < nB) {                                   // ---- dWx0: 16 gate rows (4 per quarter of the block) x 64 e, K = V
+        // (64-wide e tiles: with 128 the emb tile alone was 64 KB of LDS, which kept this launch -- three per step, one of
+        // them in the step's exposed tail -- from sharing a CU with the GEMM blocks around it: 33-44 us per launch in the
+        // step against ~10 alone)
+        const int etiles64 = (E + 63) >> 6;
+        const int et = bid % etiles64, g0 = (bid / etiles64) * 16;
+        const int e64 = tid & 63, q = tid >> 6;
+        const int e0 = et * 64, e = e0 + e64;
         float* tt = sh;                               // dT^T tile [V][16]
-        float* em = sh + 128 * 16;                    // emb tile  [V][128]
+        float* em = sh + 128 * 16;                    // emb tile  [V][64]
         for (int i = tid; i < V * 16; i += 256) tt[i] = dT[(long)(i >> 4) * G + g0 + (i & 15)];
-        for (int i = tid; i < V * 128; i += 256) {
-            const int v = i >> 7, ee = i & 127;
+        for (int i = tid; i < V * 64; i += 256) {
+            const int v = i >> 6, ee = i & 63;
             em[i] = (e0 + ee < E) ? emb[(long)v * E + e0 + ee] : 0.f;
         }
         __syncthreads();
         if (e < E) {
-            float acc[8];
+            float acc[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            for (int i = 0; i < 4; ++i) acc[i] = 0.f;
 #pragma unroll 4
             for (int v = 0; v < V; ++v) {
-                const float x = em[v * 128 + e_l];
+                const float x = em[v * 64 + e64];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(tt[v * 16 + half * 8 + i], x, acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(tt[v * 16 + q * 4 + i], x, acc[i]);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) atomicAdd(dWx0 + (long)(g0 + half * 8 + i) * ldw + e, acc[i]);   // atomic: two
+            for (int i = 0; i < 4; ++i) atomicAdd(dWx0 + (long)(g0 + q * 4 + i) * ldw + e, acc[i]);   // atomic: two
             // chunks' tables may be folded at the same time on different streams (engine: side and main)
         }
         return;
@@ -409,8 +414,8 @@ extern "C" int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw,
     if (V <= 0 || V > 128 || E <= 0 || G <= 0 || (G % 16) != 0 || ldw < E) return ARCVAE_ERR_ARG;
     if ((G % TF_KS) != 0) return ARCVAE_ERR_ARG;
     const int etiles = ceil_div(E, 128);
-    const int nA = ceil_div(V, TF_ROWS) * etiles * (G / TF_KS), nB = (G / 16) * etiles, nC = ceil_div(G, 256);
-    const size_t lds = sizeof(float) * (size_t)max(TF_KS * 128 + TF_ROWS * TF_KS + TF_ROWS * 128, 128 * 16 + 128 * 128);
+    const int nA = ceil_div(V, TF_ROWS) * etiles * (G / TF_KS), nB = (G / 16) * ceil_div(E, 64), nC = ceil_div(G, 256);
+    const size_t lds = sizeof(float) * (size_t)max(TF_KS * 128 + TF_ROWS * TF_KS + TF_ROWS * 128, 128 * 16 + 128 * 64);
     hipLaunchKernelGGL(table_finalize_kernel, dim3(nA + nB + nC), dim3(256), lds, stream, dT, Wx0, ldw, emb, dEmb, dWx0,
                        db0, V, E, G, nA, nB, etiles);
     return arcvae_launch_status();

@@ -23,7 +23,7 @@
 // internal (C++ linkage): grouped weight-gradient GEMMs, see gemm.hip
 int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* const* A, int lda,
                                const float* const* B, int ldb, float* const* C, int ldc, int allow_split,
-                               hipStream_t stream);
+                               float* const* colsum /* optional: colsum_i[M] += column sums of A_i */, hipStream_t stream);
 
 // internal (C++ linkage): throughput mode, weight gradients from octet-major bf16 operand copies, see gemm.hip
 int arcvae_wgrad_octet_group(int n, int M, int N, const int* K, const void* const* A, const void* const* B,
