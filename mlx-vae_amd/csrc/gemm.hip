@@ -978,12 +978,15 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
         bool ok = true;
         for (int i = 0; i < n; ++i) ok = ok && K[i] > 0 && split_tn_ok(M, N, A[i], lda, B[i], ldb);
         if (ok) {
+            const bool ride = arcvae_env_int("ARCVAE_COLSUM_FUSED", 1) != 0;   // 0: column sums by launch (A/B experiments)
             SplitTN q[ARCVAE_SPLIT_GROUP_MAX];
             for (int i = 0; i < n; ++i) {
-                q[i].A = A[i]; q[i].B = B[i]; q[i].C = C[i]; q[i].colsum = colsum ? colsum[i] : nullptr; q[i].M = M; q[i].N = N; q[i].K = K[i];
+                q[i].A = A[i]; q[i].B = B[i]; q[i].C = C[i]; q[i].colsum = (colsum && ride) ? colsum[i] : nullptr; q[i].M = M; q[i].N = N; q[i].K = K[i];
                 q[i].lda = lda; q[i].ldb = ldb; q[i].ldc = ldc; q[i].kchunk = 0;
             }
-            return launch_split_tn_group(n, q, (allow_split & 2) != 0, (allow_split & 4) != 0, stream);
+            const int rc = launch_split_tn_group(n, q, (allow_split & 2) != 0, (allow_split & 4) != 0, stream);
+            if (rc || ride) return rc;
+            return colsums_by_launch();
         }
     }
     bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0;
