@@ -50,11 +50,19 @@ def test_committed_bench_line_has_every_contract_field():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    # the legs reported NEXT TO the fp32 headline (never instead of it): strong scaling, throughput mode, configs[2]
+    s = d["strong"]
+    assert s["global_batch"] == 2048 and s["scaling"] == "strong" and s["value"] > 0
+    b = d["bf16_mode"]
+    assert b["dtype"] == "bf16" and b["ms_per_step"] > 0 and "tolerance" in b and "NOT" in b["tolerance"]
+    o = d["other_configs"]["configs[2]"]
+    assert o["fp32"]["dtype"] == "f32" and o["bf16"]["dtype"] == "bf16"
+    assert 0.0 < o["fp32"]["frac_of_f32_mfma_peak"] < 1.0 and 0.0 < o["bf16"]["frac_of_bf16_mfma_peak"] < 1.0
 
 
 def test_bench_source_names_the_contract_fields():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for k in ('"metric"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"',
               '"roofline"', '"cpu_baseline"', '"workload"', '"strong"', '"n_ranks_seen"', '"step_tflops_executed"',
-              '"tick_model"', '"limiter"'):
+              '"tick_model"', '"limiter"', '"bf16_mode"', '"other_configs"'):
         assert k in src, k
