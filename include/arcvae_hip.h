@@ -45,6 +45,9 @@ extern "C" {
 #define ARCVAE_GEMM_BF16 256      /* throughput mode: operands rounded to bf16 (RNE), f32 accumulate on v_mfma_f32_32x32x16_bf16;
                                    * NOT a parity path (SURVEY.md section 8(d) Config 2 "bf16-in/fp32-acc"); products with M <= 256
                                    * rows on the dependent chain keep the f32 skinny kernel */
+#define ARCVAE_GEMM_SPLIT3 512    /* any layout: every f32 operand as three bf16 pieces (8+8+8 bits), the six products of weight
+                                   * >= 2^-16 on v_mfma_f32_32x32x16_bf16, f32 accumulate -- the accuracy class of the exact-f32
+                                   * kernels (a PARITY path) at 2.7x less matrix-pipe time; for GEMMs beside a persistent sweep */
 #define ARCVAE_LSTM_RETILE 1      /* arcvae_enc_lstm_backward flags bit 0: write the BPTT weight layouts first */
 #define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags bit 1: throughput mode -- bf16 operand copies and
                                    * v_mfma_f32_16x16x32_bf16 products where the shape runs on the register-tiled step kernels
@@ -56,6 +59,8 @@ extern "C" {
                                    * bit 1: throughput mode for the persistent sweeps -- the 4x4 MFMA blocks (H 256, B <= 64
                                    * forward, B <= 128 BPTT) on v_mfma_f32_4x4x4_16b_bf16, weights and h / dG rounded to bf16
                                    * on their way into the instruction */
+#define ARCVAE_DEC_SPLIT3 512     /* arcvae_dec_forward_dense `mode` bit 9 / arcvae_dec_backward_dense `flags` bit 9: the B*V-row
+                                   * products with ARCVAE_GEMM_SPLIT3 (fp32-class accuracy, less matrix-pipe time beside a sweep) */
 #define ARCVAE_DEC_BF16 256       /* arcvae_dec_forward_dense `mode` bit 8 / arcvae_dec_backward_dense `flags` bit 8: the B*V-row
                                    * products with ARCVAE_GEMM_BF16 */
 

@@ -229,6 +229,15 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
          d.C, float(free_bits), comb_ready, s)
 
 
+def _dec_gemm_bits(ws) -> int:
+    """How the decoder's B*V-row products run: throughput mode -> bf16 operands; beside the one-row-group persistent sweeps
+    (Workspace.dec_split3, set by StepEngine.workspace) -> three bf16 pieces / six products: fp32-class accuracy at 2.7x less
+    matrix-pipe time, in 32- instead of 64-cycle instructions, on the SIMDs the forward sweep's waves issue on."""
+    if ws.bf16_parts & 2:
+        return _lib.DEC_BF16
+    return _lib.DEC_SPLIT3 if getattr(ws, "dec_split3", False) else 0
+
+
 def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: int = 0,
                           temperature: float = 1.0) -> None:
     """models/decoder.py:152-175 for all B*V (row, token) pairs."""
@@ -236,7 +245,7 @@ def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: in
     bs, _k2 = _layer_ptrs(dec, d.L, "bias")
     call("arcvae_dec_forward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
          ptr(dec.p("fc_out.bias")), ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.logits),
-         ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode | (_lib.DEC_BF16 if ws.bf16_parts & 2 else 0),
+         ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode | _dec_gemm_bits(ws),
          float(temperature), stream_ptr())
 
 
@@ -257,7 +266,7 @@ def decoder_backward(dec: ParamStore, ws: Workspace, d: ModelDims, inv_count: fl
     call("arcvae_dec_backward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
          ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.dlogits), ptr(ws.ddh), ptr(ws.ddG),
          ptr(ws.dtableD), ptr(ws.wcpart), ptr(dec.g("embedding.weight")), dwx, dbs, ptr(dec.g("fc_out.weight")),
-         ptr(dec.g("fc_out.bias")), ws.B, d.V, d.E, d.C, d.H, d.L, _lib.DEC_BF16 if ws.bf16_parts & 2 else 0, s)
+         ptr(dec.g("fc_out.bias")), ws.B, d.V, d.E, d.C, d.H, d.L, _dec_gemm_bits(ws), s)
 
 
 def latent_loss(ws: Workspace, d: ModelDims, free_bits: float, with_grads: bool) -> None:
@@ -826,6 +835,10 @@ class StepEngine:
                 return self._ws[(B, T, True)]
             ws = Workspace(self.d, B, T, self.device, train)
             ws.bf16 = self.precision == "bf16"
+            # the decoder's GEMMs run beside the forward sweep: in their three-piece form where that sweep is the persistent
+            # one-row-group kernel (0.991 -> 0.976 ms at bs 64; with more rows per GPU the exact-f32 tile GEMM is ahead:
+            # bs 128 1.730 vs 1.758, bs 256 3.27 vs 3.38; ARCVAE_DEC_SPLIT3=0/1 overrides)
+            ws.dec_split3 = os.environ.get("ARCVAE_DEC_SPLIT3", "1" if (B <= 64 and persistent_forward_ok(ws, self.d)) else "0") == "1"
             ws.bf16_parts = int(os.environ.get("ARCVAE_BF16_PARTS", "7")) if ws.bf16 else 0   # ablation: 1 sweeps, 2 decoder, 4 weight gradients
             if (train and (ws.bf16_parts & 5) == 5 and B % 16 == 0 and os.environ.get("ARCVAE_BF16_OCT", "1") != "0"
                     and _lib.load().arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3

@@ -338,8 +338,9 @@ extern "C" int arcvae_dec_forward_dense(const float* emb, const float* const* Wx
         return ARCVAE_ERR_ARG;
     if (B <= 0 || V <= 0 || E <= 0 || C < 0 || C > MAXC || H <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS)
         return ARCVAE_ERR_ARG;
-    const int BF = (mode & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : 0;   // throughput mode: the B*V-row products on bf16 operands
-    mode &= ~ARCVAE_DEC_BF16;
+    // the B*V-row products: throughput mode = bf16 operands; ARCVAE_DEC_SPLIT3 = three bf16 pieces, six products (fp32-class)
+    const int BF = (mode & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : ((mode & ARCVAE_DEC_SPLIT3) ? ARCVAE_GEMM_SPLIT3 : 0);
+    mode &= ~(ARCVAE_DEC_BF16 | ARCVAE_DEC_SPLIT3);
     if (mode == 1 && !(temperature > 0.f)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
         if (!Wx[l] || !bias[l]) return ARCVAE_ERR_ARG;
@@ -422,8 +423,8 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
     const int G = 4 * H;
     const long R = (long)B * V;
     const int Ri = (int)R;
-    const int BF = (flags & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : 0;
-    const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | BF;
+    const int BF = (flags & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : ((flags & ARCVAE_DEC_SPLIT3) ? ARCVAE_GEMM_SPLIT3 : 0);
+    const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | (BF & ARCVAE_GEMM_BF16);   // (TN "+=": the split TN kernel either way)
     float* dhA = dh;
     float* dhB = dh + R * H;
     const float* hTop = hact + (long)(L - 1) * R * H;

@@ -29,6 +29,14 @@ __device__ __forceinline__ unsigned split_pk(float a, float b) {   // v_cvt_pk_b
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
+// (x0, x1) -> packed bf16 pairs hi, mid, lo with x = hi + mid + lo (the two subtractions are exact in f32)
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = split_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = split_pk(r0, r1);
+    lo = split_pk(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
+}
+
 struct GemmP {
     const float* A;
     const float* B;
@@ -259,33 +267,48 @@ struct BfLoader {
         }
     }
 
-    __device__ __forceinline__ void store(__bf16* S, int tid) const {
+    // 8 consecutive k of one row -> its LDS slot(s).  PIECES = 1: rounded to bf16.  PIECES = 3: the hi / mid / lo pieces
+    // (x = hi + mid + lo) into three images `img` elements apart (the split form: fp32-class accuracy, six products).
+    template <int PIECES>
+    __device__ __forceinline__ static void put8(__bf16* dst, const float* x, int img) {
+        if constexpr (PIECES == 1) {
+            *reinterpret_cast<u32x4_g*>(dst) = u32x4_g{split_pk(x[0], x[1]), split_pk(x[2], x[3]), split_pk(x[4], x[5]), split_pk(x[6], x[7])};
+        } else {
+            u32x4_g h, m, l;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                unsigned a, b, c;
+                split3(x[2 * d], x[2 * d + 1], a, b, c);
+                h[d] = a; m[d] = b; l[d] = c;
+            }
+            *reinterpret_cast<u32x4_g*>(dst) = h;
+            *reinterpret_cast<u32x4_g*>(dst + img) = m;
+            *reinterpret_cast<u32x4_g*>(dst + 2 * img) = l;
+        }
+    }
+    template <int PIECES = 1>
+    __device__ __forceinline__ void store(__bf16* S, int tid, int img = 0) const {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             if constexpr (KCONTIG) {
                 const int idx = tid + i * 256, r = idx / (BKT / 8), o = idx % (BKT / 8);
-                const u32x4_g w = {split_pk(v[i][0], v[i][1]), split_pk(v[i][2], v[i][3]), split_pk(v[i][4], v[i][5]),
-                                   split_pk(v[i][6], v[i][7])};
-                *reinterpret_cast<u32x4_g*>(S + r * LDK + 8 * o) = w;
+                put8<PIECES>(S + r * LDK + 8 * o, v[i], img);
             } else {
                 const int o = (tid >> 6) + 4 * i, r = VW * (tid & 63);
 #pragma unroll
-                for (int j = 0; j < VW; ++j) {
-                    const u32x4_g w = {split_pk(v[i][8 * j + 0], v[i][8 * j + 1]), split_pk(v[i][8 * j + 2], v[i][8 * j + 3]),
-                                       split_pk(v[i][8 * j + 4], v[i][8 * j + 5]), split_pk(v[i][8 * j + 6], v[i][8 * j + 7])};
-                    *reinterpret_cast<u32x4_g*>(S + (r + j) * LDK + 8 * o) = w;
-                }
+                for (int j = 0; j < VW; ++j) put8<PIECES>(S + (r + j) * LDK + 8 * o, v[i] + 8 * j, img);
             }
         }
     }
 };
 
-template <int BM, int BN, bool AK, bool BKC, int BKT>
+template <int BM, int BN, bool AK, bool BKC, int BKT, int PIECES = 1>
 __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int bx, const int by, const int bz, const bool split,
                                                __bf16* smem) {
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32, LDK = BKT + 8;
-    __bf16* const As0 = smem;                       // As[buf] = As0 + buf * BM * LDK
-    __bf16* const Bs0 = smem + 2 * BM * LDK;        // Bs[buf] = Bs0 + buf * BN * LDK
+    constexpr int IA = BM * LDK, IB = BN * LDK;     // one operand image; a buffer holds PIECES of them
+    __bf16* const As0 = smem;                       // As[buf][piece] = As0 + (buf * PIECES + piece) * IA
+    __bf16* const Bs0 = smem + 2 * PIECES * IA;     // Bs[buf][piece] = Bs0 + (buf * PIECES + piece) * IB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = by * BM, n0 = bx * BN;
@@ -306,8 +329,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int bx, con
     if (nk > 0) {
         la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
         lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-        la.store(As0, tid);
-        lb.store(Bs0, tid);
+        la.template store<PIECES>(As0, tid, IA);
+        lb.template store<PIECES>(Bs0, tid, IB);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -316,24 +339,36 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int bx, con
             la.load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BKT, kend, tid);
             lb.load(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BKT, kend, tid);
         }
-        const __bf16* as = As0 + cur * BM * LDK + (wm * WM + (lane & 31)) * LDK + 8 * (lane >> 5);
-        const __bf16* bs = Bs0 + cur * BN * LDK + (wn * WN + (lane & 31)) * LDK + 8 * (lane >> 5);
+        const __bf16* as = As0 + cur * PIECES * IA + (wm * WM + (lane & 31)) * LDK + 8 * (lane >> 5);
+        const __bf16* bs = Bs0 + cur * PIECES * IB + (wn * WN + (lane & 31)) * LDK + 8 * (lane >> 5);
 #pragma unroll
         for (int kk = 0; kk < BKT; kk += 16) {
-            bf16x8_t a[MT], b[NT];
+            bf16x8_t a[PIECES][MT], b[PIECES][NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(as + i * 32 * LDK + kk);
+            for (int q = 0; q < PIECES; ++q) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bs + j * 32 * LDK + kk);
+                for (int i = 0; i < MT; ++i) a[q][i] = *reinterpret_cast<const bf16x8_t*>(as + q * IA + i * 32 * LDK + kk);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[q][j] = *reinterpret_cast<const bf16x8_t*>(bs + q * IB + j * 32 * LDK + kk);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    f32x16 c = acc[i][j];
+                    if constexpr (PIECES == 3) {   // the six terms of weight >= 2^-16, small ones first (pieces: 0 hi, 1 mid, 2 lo)
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PIECES - 1][i], b[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[PIECES - 1][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PIECES > 1 ? 1 : 0][i], b[PIECES > 1 ? 1 : 0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PIECES > 1 ? 1 : 0][i], b[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[PIECES > 1 ? 1 : 0][j], c, 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+                }
         }
         if (kt + 1 < nk) {
-            la.store(As0 + (cur ^ 1) * BM * LDK, tid);
-            lb.store(Bs0 + (cur ^ 1) * BN * LDK, tid);
+            la.template store<PIECES>(As0 + (cur ^ 1) * PIECES * IA, tid, IA);
+            lb.template store<PIECES>(Bs0 + (cur ^ 1) * PIECES * IB, tid, IB);
         }
         __syncthreads();
     }
@@ -362,29 +397,29 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& p, const int bx, con
         }
 }
 
-template <int BM, int BN, bool AK, bool BKC, int BKT>
+template <int BM, int BN, bool AK, bool BKC, int BKT, int PIECES = 1>
 __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 bf_smem[];
-    gemm_bf16_body<BM, BN, AK, BKC, BKT>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z > 1, bf_smem);
+    gemm_bf16_body<BM, BN, AK, BKC, BKT, PIECES>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z > 1, bf_smem);
 }
 
-template <int BM, int BN, bool AK, bool BKC, int BKT>
+template <int BM, int BN, bool AK, bool BKC, int BKT, int PIECES = 1>
 void launch_bf16_tile(const GemmP& p, dim3 grid, hipStream_t s) {
-    const size_t lds = sizeof(__bf16) * 2 * (BM + BN) * (BKT + 8);
+    const size_t lds = sizeof(__bf16) * 2 * PIECES * (BM + BN) * (BKT + 8);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile_kernel<BM, BN, AK, BKC, BKT>,
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_tile_kernel<BM, BN, AK, BKC, BKT, PIECES>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gemm_bf16_tile_kernel<BM, BN, AK, BKC, BKT>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_tile_kernel<BM, BN, AK, BKC, BKT, PIECES>), grid, dim3(256), lds, s, p);
 }
-template <int BM, int BN, int BKT>
+template <int BM, int BN, int BKT, int PIECES = 1>
 bool launch_bf16_tile_t(const GemmP& p, dim3 grid, bool ak, bool bk, hipStream_t s) {
     const bool aok = ak ? BfLoader<BM, true, BKT>::ok(p.A, p.lda, p.M, p.K) : BfLoader<BM, false, BKT>::ok(p.A, p.lda, p.M, p.K);
     const bool bok = bk ? BfLoader<BN, true, BKT>::ok(p.B, p.ldb, p.N, p.K) : BfLoader<BN, false, BKT>::ok(p.B, p.ldb, p.N, p.K);
     if (!aok || !bok) return false;
-    if (ak && bk) launch_bf16_tile<BM, BN, true, true, BKT>(p, grid, s);
-    else if (ak) launch_bf16_tile<BM, BN, true, false, BKT>(p, grid, s);
-    else if (bk) launch_bf16_tile<BM, BN, false, true, BKT>(p, grid, s);
-    else launch_bf16_tile<BM, BN, false, false, BKT>(p, grid, s);
+    if (ak && bk) launch_bf16_tile<BM, BN, true, true, BKT, PIECES>(p, grid, s);
+    else if (ak) launch_bf16_tile<BM, BN, true, false, BKT, PIECES>(p, grid, s);
+    else if (bk) launch_bf16_tile<BM, BN, false, true, BKT, PIECES>(p, grid, s);
+    else launch_bf16_tile<BM, BN, false, false, BKT, PIECES>(p, grid, s);
     return true;
 }
 
@@ -465,13 +500,6 @@ struct SplitTNGroup {
     int n;
 };
 
-// (x0, x1) -> packed bf16 pairs hi, mid, lo with x = hi + mid + lo (the two subtractions are exact in f32)
-__device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = split_pk(x0, x1);
-    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-    mid = split_pk(r0, r1);
-    lo = split_pk(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
-}
 
 // Block = 4 waves on ONE 128 x 32*NJ output tile: the waves take the K = 16 steps of the block's K chunk round-robin
 // (the outputs are small and K is long, so parallelism has to come from K; split-K over blocks alone would multiply
@@ -853,6 +881,23 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
         SplitTN q;
         q.A = A; q.B = B; q.C = C; q.colsum = nullptr; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.kchunk = 0;
         return launch_split_tn_group(1, &q, (flags & ARCVAE_GEMM_TILE_WIDE) != 0, (flags & ARCVAE_GEMM_BF16) != 0, stream);
+    }
+    // ARCVAE_GEMM_SPLIT3: any layout on the bf16 matrix pipe at fp32-class accuracy -- three bf16 pieces per operand, six
+    // products, 64 x 64 tiles (61 KB of LDS).  For GEMMs that run BESIDE a persistent sweep: 2.7x less matrix-pipe time
+    // than the exact-f32 form, in 32-cycle instead of 64-cycle instructions, on the SIMDs the chain's waves issue on.
+    if ((flags & ARCVAE_GEMM_SPLIT3) && !(flags & ARCVAE_GEMM_BF16) && !(transA == 0 && M <= 256)) {
+        dim3 grid(ceil_div(N, 64), ceil_div(M, 64), 1);
+        if ((flags & ARCVAE_GEMM_SPLITK) && p.act == 0) {
+            static const int target3 = arcvae_env_int("ARCVAE_SPLITK_BLOCKS", 512);
+            int z = min(ceil_div(target3, (int)(grid.x * grid.y)), max(1, K / 256));
+            if (z > 1) {
+                p.kchunk = ceil_div(ceil_div(K, z), 64) * 64;
+                grid.z = ceil_div(K, p.kchunk);
+                if (!p.accumulate && arcvae_zero(C, M, N, ldc, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+            }
+        }
+        if (launch_bf16_tile_t<64, 64, 32, 3>(p, grid, ak, bk, stream)) return arcvae_launch_status();
+        p.kchunk = ((K + BK - 1) / BK) * BK;     // operands not vector-loadable: the f32 kernels below
     }
     // throughput mode: bf16 operands, f32 accumulate (everything but the minibatch-sized products on the chain, which
     // are latency-bound: they keep the skinny f32 path below)

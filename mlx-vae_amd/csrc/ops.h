@@ -13,11 +13,13 @@
 #define ARCVAE_GEMM_DTANH 64    /* C = (A.B) * (1 - T^2), T = `bias` read as an [M,ldc] matrix (tanh backward) */
 #define ARCVAE_GEMM_TILE_WIDE 128 /* split-bf16 TN path: 128-row tile (the caller knows no persistent sweep is resident) */
 #define ARCVAE_GEMM_BF16 256      /* throughput mode: operands rounded to bf16, f32 accumulate (not a parity path) */
+#define ARCVAE_GEMM_SPLIT3 512    /* three bf16 pieces per operand, six products: fp32-class accuracy on the bf16 matrix pipe */
 
 #define ARCVAE_LSTM_RETILE 1      /* arcvae_enc_lstm_backward flags: write the BPTT weight layouts first */
 #define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime only) */
 
 #define ARCVAE_PERSIST_BF16 2     /* arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags bit 1: throughput mode */
+#define ARCVAE_DEC_SPLIT3 512      /* same places: the B*V-row products with ARCVAE_GEMM_SPLIT3 (a parity path) */
 #define ARCVAE_DEC_BF16 256        /* arcvae_dec_forward_dense `mode` bit / arcvae_dec_backward_dense `flags` bit: throughput mode */
 
 // internal (C++ linkage): grouped weight-gradient GEMMs, see gemm.hip

@@ -93,6 +93,39 @@ def test_bf16_mode_gemm_rounds_operands_only(tA, tB, M, N, K, flags):
     assert (np.abs(got - exact) / mag).max() > 1e-5               # the bf16 path did run
 
 
+@pytest.mark.parametrize("tA,tB,M,N,K,flags", [(0, 1, 5120, 1024, 256, 0), (0, 0, 5120, 256, 1024, 0), (0, 1, 640, 80, 256, 0),
+                                                (1, 0, 512, 256, 1000, 1), (1, 1, 300, 130, 72, 2), (0, 0, 1000, 512, 80, 0)])
+def test_three_piece_gemm_has_f32_accuracy(tA, tB, M, N, K, flags):
+    """ARCVAE_GEMM_SPLIT3 (gemm_bf16_tile_kernel with three bf16 pieces per operand, six products): any layout, the accuracy
+    class of the exact-f32 MFMA kernel on the same data: worst element error relative to sum|a||b| within 2x the f32 kernel's
+    (plus a floor), and the same standing against the 1e-4 / 1e-6 element-wise parity criterion."""
+    from arcvae_hip import _lib
+    from helpers import elem_err
+    rs = np.random.RandomState(2 * M + N + K)
+    A = (rs.standard_normal((K, M) if tA else (M, K)) * np.exp(rs.uniform(-2, 2, size=(1, M) if tA else (M, 1)))).astype(np.float32)
+    Bm = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    C0 = rs.standard_normal((M, N)).astype(np.float32)
+    opA, opB = (A.T if tA else A).astype(np.float64), (Bm.T if tB else Bm).astype(np.float64)
+    ref = opA @ opB + bias
+    if flags & 1:
+        ref = ref + C0
+    if flags & 2:
+        ref = np.tanh(ref)
+    mag = np.abs(opA) @ np.abs(opB) + 1.0
+    dA, dB, db = _dev(A), _dev(Bm), _dev(bias)
+    err, frac = {}, {}
+    for name, extra in (("split3", _lib.GEMM_SPLIT3), ("f32", 0)):
+        dC = _dev(C0)
+        _lib.gemm(bool(tA), bool(tB), M, N, K, dA, A.shape[1], dB, Bm.shape[1], dC, N, db, flags | extra | _lib.GEMM_NO_SKINNY)
+        torch.cuda.synchronize()
+        got = dC.cpu().numpy().astype(np.float64)
+        err[name] = (np.abs(got - ref) / mag).max()
+        frac[name] = elem_err(got, ref, 1e-4, 1e-6)[0]           # worst element as a fraction of the parity bound
+    assert err["split3"] <= max(2.0 * err["f32"], 3e-7), err
+    assert frac["split3"] <= max(1.5 * frac["f32"], 0.3), frac   # (K = 1024 with this dynamic range: both sit near 0.2)
+
+
 def test_gemm_strided_c():
     """C with ldc > N and B with ldb > K (the decoder's Wx0[:, :E] sub-block)."""
     from arcvae_hip import _lib
