@@ -344,11 +344,6 @@ class Gates:
         return self._probed[key]
 
 
-def _capturing() -> bool:
-    """The current stream is being captured into a hipGraph (tests replace this)."""
-    return torch.cuda.is_current_stream_capturing()
-
-
 class SegmentRunner:
     """Runs named launch sequences on given streams -- eagerly, or captured ONCE each as a single-stream
     hipGraph and replayed.  Single-stream (linear) segments with eager events between them are used instead
@@ -360,12 +355,11 @@ class SegmentRunner:
         self._g: Dict[str, object] = {}
         self._cap_stream: Optional[torch.cuda.Stream] = None  # capture may not happen on the default stream
 
-    def __call__(self, key: str, fn, stream: torch.cuda.Stream) -> bool:
-        """Returns True when the segment was REPLAYED from its graph (False: `fn` ran eagerly in this call)."""
+    def __call__(self, key: str, fn, stream: torch.cuda.Stream) -> None:
         with torch.cuda.stream(stream):
             if not self.capture:
                 fn()
-                return False
+                return
             g = self._g.get(key)
             if g is None:
                 fn()  # first step runs eagerly (its results are this step's results) ...
@@ -385,8 +379,6 @@ class SegmentRunner:
                 fn()
             else:
                 g.replay()
-                return True
-        return False
 
 
 class EncoderBackwardPlan:
@@ -524,7 +516,7 @@ class EncoderBackwardPlan:
 
 def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
                      run=_inline, prologue=None, after_first=None, aux2: Optional[torch.cuda.Stream] = None,
-                     gates: Optional[Gates] = None, epilogue=None) -> None:
+                     gates: Optional[Gates] = None) -> None:
     """Backward of heads + LSTM stack on (current stream, aux).  `prologue` (optional) is enqueued at the head
     of the first main-stream segment (used to fuse encoder forward + loss into it); `after_first` (optional) is
     called on the host right after that first segment has been enqueued (the decoder is enqueued there: early
@@ -544,7 +536,8 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
             after_first()
         return
     if gates is not None:
-        return _encoder_backward_gated(plan, ws, aux, aux2, run, prologue, after_first, gates, epilogue)
+        _encoder_backward_gated(plan, ws, aux, aux2, run, prologue, after_first, gates)
+        return
     for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
         def main_seg(c=c, s0=s0, s1=s1):
             if c == 0:
@@ -585,24 +578,20 @@ def _tables_on_main(plan, ws) -> bool:
 
 
 def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2, run, prologue, after_first,
-                            g: Gates, epilogue=None) -> bool:
+                            g: Gates) -> None:
     """encoder_backward with device-side gates instead of event waits (class Gates).  Main's signals of a step:
     #1 inputs ready (enqueued by the caller), #(2+c) after sweep chunk c, the last chunk topping P up to a multiple
     of STRIDE.  aux: chunk c runs behind signal #(2+c); it signals Q once (after its last-but-one chunk).  side:
     the tail chunk's token-table half runs behind Q (the table accumulates across aux's earlier chunks) and the last
     signal.  aux and side report their last piece of the step on R; the current stream joins them with a gate
-    on R at the very end (the decoder segment precedes side's tail piece in stream order, so R covers it too).
-    `epilogue` (optional): the step's finish (join gate, loss scalars, optimizer) as the END of main's segment instead of a
-    segment of its own -- the seam between two graph launches on one stream was ~10 us of the exposed tail
-    (profiles/r02_tail_timeline.txt).  Returns True when the epilogue ran as part of main's segment in this step, i.e. when
-    that segment was replayed from its graph; otherwise the caller enqueues the finish itself."""
+    on R at the very end (the decoder segment precedes side's tail piece in stream order, so R covers it too)."""
     main = torch.cuda.current_stream()
     nc = len(plan.chunks)
     if nc + 1 > g.STRIDE:
         raise ValueError("too many BPTT chunks for the gate stride")
     if getattr(plan, "fused", False) and nc == 1 and aux2 is not None:
         _encoder_backward_gated_fused(plan, ws, aux, aux2, run, prologue, after_first, g)
-        return False
+        return
     tail_on_side = aux2 is not None and nc >= 2
     # Since the persistent sweeps the weight-gradient stream, not the chain, ends the step (aux is busy without a gap
     # from the end of chunk 0 to the end of the step): the token-table half of EVERY chunk goes to side, which is idle
@@ -639,14 +628,8 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
         if own_tables:
             _s0, _s1, t_lo_l, t_hi_l, _f, _l = plan.chunks[-1]
             plan.wgrad(t_lo_l, t_hi_l, True, True, 2 | 32 | pre_zeroed(), table=getattr(ws, "dtable1", None))
-        if take_epilogue and _capturing():
-            # only in the RECORDED segment: the eager first run of a segment is followed by a host synchronize
-            # (SegmentRunner), and the join gate in it would wait for aux / side segments the host has not enqueued yet
-            epilogue()
 
-    # the finish can ride in main's segment when main joins aux / side through the gate on R (two or more chunks)
-    take_epilogue = epilogue is not None and nc >= 2 and aux2 is not None
-    replayed = run("main", main_seg, main)
+    run("main", main_seg, main)
     if after_first:
         after_first()
     for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
@@ -688,7 +671,6 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
         run(f"aux{c}", aux_seg, aux)
     if aux2 is not None and not tail_on_side:
         main.wait_stream(aux2)  # single-chunk sweeps (T <= 3): side only ran the decoder and reported nothing
-    return bool(take_epilogue and replayed)   # the finish ran inside main's segment in THIS step (graph replay)
     # The caller's next main-stream segment must BEGIN with `Gates.join(g)`: main polls R there (a gate reacts within
     # ~2 us; an event wait on two other queues cost ~20 us of the exposed tail).
 
@@ -954,7 +936,7 @@ class StepEngine:
         self.ev_enc_fwd.record(torch.cuda.current_stream())
 
     def enqueue_backward(self, ws: Workspace, run=_inline, fuse_forward: bool = False, after_first=None,
-                         gates: Optional[Gates] = None, start_signal=None, epilogue=None) -> bool:
+                         gates: Optional[Gates] = None, start_signal=None) -> None:
         """`stats[:2Z+3]` holds GLOBAL sums (or, with fuse_forward, will: single process): latent loss scalars
         and gradients, then the encoder backward.  Does NOT wait for the decoder."""
         fb = float(self.hyper_host["free_bits"])
@@ -967,9 +949,8 @@ class StepEngine:
         # the tail chunk's token-table half goes to the SIDE stream: the decoder finished long ago and, unlike a
         # fourth stream, `side` owns a hardware queue of its own (HIP maps streams onto 4 queues), so the two
         # halves really run side by side
-        # (epilogue: the step's finish as the end of main's gated segment; True is returned when it was taken)
-        return bool(encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue,
-                                     after_first=after_first, aux2=self.side, gates=gates, epilogue=epilogue))
+        encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue, after_first=after_first,
+                         aux2=self.side, gates=gates)
 
     def enqueue_recon(self, ws: Workspace, run=_inline) -> None:
         """stats[2Z+3] = sum of this process's CE row sums (after the decoder's TF walk)."""
@@ -981,10 +962,8 @@ class StepEngine:
         call("arcvae_stats_set_recon", ptr(ws.rowloss), ws.B, ptr(ws.stats), self.d.Z, stream_ptr())
 
     def enqueue_finish(self, ws: Workspace, lr: float, update: bool, run=_inline, with_recon: bool = False,
-                       dec_adam: bool = True, join_side: bool = True, gates: Optional[Gates] = None,
-                       build_only: bool = False):
-        """[join ->] [CE sum ->] recon/total scalars, both Adam updates: one segment (build_only: return the segment's
-        body instead of enqueueing it -- the gated single-process step appends it to main's backward segment)."""
+                       dec_adam: bool = True, join_side: bool = True, gates: Optional[Gates] = None) -> None:
+        """[join ->] [CE sum ->] recon/total scalars, both Adam updates: one segment."""
         main = torch.cuda.current_stream()
         if join_side:
             main.wait_stream(self.side)
@@ -1003,10 +982,7 @@ class StepEngine:
                     adam_update(self.dec, lr, guards=(ga, gb))
                 adam_update(self.enc, lr, guards=(ga, gb))
 
-        if build_only:
-            return fin
         run(("finish" if update else "finish_noupdate") + ("_r" if with_recon else ""), fin, main)
-        return None
 
     def _enqueue_step(self, ws: Workspace, lr: float, global_rows: int, update: bool, run=_inline) -> None:
         """Single-process step.  Host enqueue order: the decoder segment (one short graph launch; it overlaps the
@@ -1019,7 +995,7 @@ class StepEngine:
             nc = len(EncoderBackwardPlan(self.enc, ws, self.d).chunks)
 
             def grun(key, fn, stream, _run=run):             # gated segments are recorded under their own names
-                return _run(f"gated:{key}", fn, stream)
+                _run(f"gated:{key}", fn, stream)
 
             # Signal #1 ("inputs ready": releases the decoder on side) is raised by the forward sweep when it starts.
             # The main segment -- encoder forward + loss + dcomb + the whole BPTT chain, no seam in it -- is enqueued
@@ -1031,16 +1007,9 @@ class StepEngine:
                 self.enqueue_decoder(ws, global_rows, grun, wait_current=False, split_events=False, gate=(g, nc < 2),
                                      adam_lr=lr if update else None)
 
-            # the finish (join gate, loss scalars, encoder Adam) rides at the END of main's segment where the backward allows
-            # it: a segment of its own cost ~10 us of graph-launch seam in the exposed tail (ARCVAE_FINISH_IN_MAIN=0: as before)
-            fin = None
-            if os.environ.get("ARCVAE_FINISH_IN_MAIN", "1") != "0":
-                fin = self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False, gates=g,
-                                          build_only=True)
-            took = self.enqueue_backward(ws, grun, gates=g, fuse_forward=True, after_first=dec_after_main,
-                                         start_signal=g.word(g.P), epilogue=fin)
-            if not took:
-                self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False, gates=g)
+            self.enqueue_backward(ws, grun, gates=g, fuse_forward=True, after_first=dec_after_main,
+                                  start_signal=g.word(g.P))
+            self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False, gates=g)
             return
         self.side.wait_stream(main)                          # the decoder only has to follow the input copies
         self.enqueue_decoder(ws, global_rows, run, wait_current=False, split_events=False)

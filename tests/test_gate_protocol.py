@@ -65,7 +65,7 @@ class _Plan:
             self.g.note("wgrad", c, parts & 15)     # bits 4, 5, 8 choose kernels / workspaces / the zero fill, not pieces
 
 
-def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False, finish_in_main=False):
+def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = _Recorder()
@@ -75,11 +75,9 @@ def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False, finish
     plan = _Plan(g, T, L, fractions, persistent)
     nc = len(plan.chunks)
 
-    def run(key, fn, stream):                    # (a recorded segment: what a graph replay executes)
+    def run(key, fn, stream):
         g.cur = stream
         fn()
-        return finish_in_main
-    monkeypatch.setattr(E, "_capturing", lambda: finish_in_main)
 
     def prologue():                              # the forward sweep raises signal #1 when it starts
         g.note("signal", E.Gates.P, 1)
@@ -96,12 +94,10 @@ def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False, finish
         g.cur = side                             # EngineOps (gated): CE sum, all-reduce of [dec.grad | CE sum] and the decoder's
         g.note("dec_reduce")                     # Adam are side's NEXT operations (stream order: no gate, no event)
         E._encoder_backward_gated(plan, None, aux, side, run, None, None, g)
-        took = False
-    else:                                        # single process: the finish (its join gate) may ride at the end of main's segment
-        took = E._encoder_backward_gated(plan, None, aux, side, run, prologue, decoder_after_main, g,
-                                         (lambda: g.join()) if finish_in_main else None)
+    else:
+        E._encoder_backward_gated(plan, None, aux, side, run, prologue, decoder_after_main, g)
     g.cur = main
-    if nc >= 2 and not took:
+    if nc >= 2:
         g.join()                                 # enqueue_finish / _join_gated
     return g.ops, (main, side, aux), nc
 
@@ -161,12 +157,10 @@ def _replay(ops, streams, steps):
                                            (40, 4, (0.1, 0.2, 0.3, 0.5, 0.7, 0.9, 1.0)), (9, 1, (0.5, 1.0)), (5, 3, (0.3, 0.6, 0.85, 1.0))])
 @pytest.mark.parametrize("dp", [False, True])
 @pytest.mark.parametrize("tables_on_main", [False, True])
-@pytest.mark.parametrize("finish_in_main", [False, True])
-def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persistent, env, dp, tables_on_main, finish_in_main,
-                                                         monkeypatch):
+def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persistent, env, dp, tables_on_main, monkeypatch):
     # tables_on_main: every chunk folds its own token table, main forms the last chunk's behind its own sweep (round 2)
     monkeypatch.setattr(E, "_tables_on_main", lambda plan, ws: tables_on_main)
-    ops, streams, nc = _record_step(T, L, fractions, persistent, env, monkeypatch, dp, finish_in_main)
+    ops, streams, nc = _record_step(T, L, fractions, persistent, env, monkeypatch, dp)
     assert nc >= 2
     steps = 5
     flags, advanced = _replay(ops, streams, steps)
