@@ -20,30 +20,43 @@ namespace {
 
 #define MAXC 8
 
-// ---- layer 0 forward: thread per (row=(b,v), unit) --------------------------------------
+// ---- layer 0 forward: block = 64 units x 4 row lanes of one token v; a thread keeps its unit's three table entries and
+// condition-weight columns in registers and walks up to 64 batch rows.  (The first form, a thread per (row, unit), read
+// Wx0[j, E + c] -- stride E + C floats between neighbouring lanes -- 3 C times per OUTPUT: 248 us per launch at the sampler's
+// bs 1024, 10x its bytes; profiles/r02_sampler_kernel_stats.csv.)  Same operation order as dec_l0_bwd_kernel's recomputation.
 __global__ __launch_bounds__(256) void dec_l0_fwd_kernel(const float* __restrict__ tableD,
                                                          const float* __restrict__ cond,
                                                          const float* __restrict__ Wx0,
                                                          const float* __restrict__ bias0, float* h0, int B,
                                                          int V, int E, int C, int H) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)B * V * H;
-    if (idx >= total) return;
-    const int unit = (int)(idx % H);
-    const long row = idx / H;
-    const int v = (int)(row % V), b = (int)(row / V);
+    const int ul = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int v = blockIdx.y, unit = blockIdx.x * 64 + ul;
+    if (unit >= H) return;
     const int ld = E + C;
-    float pre[3];
     const int gsel[3] = {0, 2, 3};  // i, g, o (forget gate is unused by the zero-state cell)
+    float base[3], bs[3], wc[3][MAXC];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int j = gsel[k] * H + unit;
-        float s = tableD[(long)v * 4 * H + j];
-        for (int c = 0; c < C; ++c) s += cond[b * C + c] * Wx0[(long)j * ld + E + c];
-        pre[k] = s + bias0[j];
+        base[k] = tableD[(long)v * 4 * H + j];
+        bs[k] = bias0[j];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) wc[k][c] = c < C ? Wx0[(long)j * ld + E + c] : 0.f;
     }
-    const float i = sigmoidf_acc(pre[0]), g = tanhf(pre[1]), o = sigmoidf_acc(pre[2]);
-    h0[idx] = o * tanhf(i * g);
+    const int bend = min(B, (int)(blockIdx.z + 1) * 64);
+    for (int b = blockIdx.z * 64 + bl; b < bend; b += 4) {
+        float pre[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float t = base[k];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) t += cond[b * C + c] * wc[k][c];
+            pre[k] = t + bs[k];
+        }
+        const float i = sigmoidf_acc(pre[0]), g = tanhf(pre[1]), o = sigmoidf_acc(pre[2]);
+        h0[((long)b * V + v) * H + unit] = o * tanhf(i * g);
+    }
 }
 
 // ---- zero-state cell on pre-activations G [R,4H] ------------------------------------------
@@ -348,7 +361,7 @@ extern "C" int arcvae_dec_forward_dense(const float* emb, const float* const* Wx
     const long R = (long)B * V;
     int rc = arcvae_gemm_f32(0, 1, V, G, E, emb, E, Wx[0], E + C, tableD, G, nullptr, 0, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(dec_l0_fwd_kernel, dim3(blocks_for(R * H)), dim3(256), 0, stream, tableD, cond, Wx[0],
+    hipLaunchKernelGGL(dec_l0_fwd_kernel, dim3(ceil_div(H, 64), V, ceil_div(B, 64)), dim3(256), 0, stream, tableD, cond, Wx[0],
                        bias[0], hact, B, V, E, C, H);
     for (int l = 1; l < L; ++l) {
         float* Gl = gpre + (long)(l - 1) * R * G;
