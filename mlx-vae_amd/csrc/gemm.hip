@@ -896,14 +896,10 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
                 if (!p.accumulate && arcvae_zero(C, M, N, ldc, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
             }
         }
-        // 128 x 128 tiles (123 KB of LDS, one block per CU: 12 LDS reads per 24 MFMAs instead of 6 per 6) where they fill the chip
-        const bool big3 = grid.z == 1 && M >= 128 && N >= 128 && ceil_div(M, 128) * ceil_div(N, 128) >= 256;
-        if (big3) {
-            dim3 grid128(ceil_div(N, 128), ceil_div(M, 128), 1);
-            if (launch_bf16_tile_t<128, 128, 32, 3>(p, grid128, ak, bk, stream)) return arcvae_launch_status();
-        } else if (launch_bf16_tile_t<64, 64, 32, 3>(p, grid, ak, bk, stream)) {
-            return arcvae_launch_status();
-        }
+        // (a 128 x 128 form -- 123 KB of LDS -- was built and dropped: no faster than the f32 128 x 128 tile where that is used,
+        // and it cannot share a CU with a persistent sweep block, which is where this flag is for: the decoder's GEMMs waited
+        // for the forward sweep to end, 0.98 -> 1.03 ms per step)
+        if (launch_bf16_tile_t<64, 64, 32, 3>(p, grid, ak, bk, stream)) return arcvae_launch_status();
         p.kchunk = ((K + BK - 1) / BK) * BK;     // operands not vector-loadable: the f32 kernels below
     }
     // throughput mode: bf16 operands, f32 accumulate (everything but the minibatch-sized products on the chain, which

@@ -95,7 +95,7 @@ def test_bf16_mode_gemm_rounds_operands_only(tA, tB, M, N, K, flags):
 
 @pytest.mark.parametrize("tA,tB,M,N,K,flags", [(0, 1, 5120, 1024, 256, 0), (0, 0, 5120, 256, 1024, 0), (0, 1, 640, 80, 256, 0),
                                                 (1, 0, 512, 256, 1000, 1), (1, 1, 300, 130, 72, 2), (0, 0, 1000, 512, 80, 0),
-                                                (0, 1, 16384, 2048, 256, 0), (0, 0, 16500, 2048, 128, 1)])   # 128 x 128 tiles
+                                                (0, 1, 16384, 2048, 256, 0), (0, 0, 16500, 2048, 128, 1)])
 def test_three_piece_gemm_has_f32_accuracy(tA, tB, M, N, K, flags):
     """ARCVAE_GEMM_SPLIT3 (gemm_bf16_tile_kernel with three bf16 pieces per operand, six products): any layout, the accuracy
     class of the exact-f32 MFMA kernel on the same data: worst element error relative to sum|a||b| within 2x the f32 kernel's
