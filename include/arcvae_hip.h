@@ -61,6 +61,8 @@ extern "C" {
                                    * on their way into the instruction */
 #define ARCVAE_DEC_SPLIT3 512     /* arcvae_dec_forward_dense `mode` bit 9 / arcvae_dec_backward_dense `flags` bit 9: the B*V-row
                                    * products with ARCVAE_GEMM_SPLIT3 (fp32-class accuracy, less matrix-pipe time beside a sweep) */
+#define ARCVAE_DEC_NO_GPRE 1024   /* arcvae_dec_forward_dense `mode` bit 10: forward only (sampler, loss-only forward) -- `gpre` is not
+                                   * written: a layer's GEMM and zero-state cell run as one kernel where the shape allows */
 #define ARCVAE_DEC_BF16 256       /* arcvae_dec_forward_dense `mode` bit 8 / arcvae_dec_backward_dense `flags` bit 8: the B*V-row
                                    * products with ARCVAE_GEMM_BF16 */
 

@@ -25,6 +25,7 @@ LSTM_BF16 = 2        # arcvae_enc_lstm_forward / _backward flags: throughput mod
 PERSIST_BF16 = 2     # arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags: throughput mode (4x4x4 bf16 blocks)
 DEC_BF16 = 256       # arcvae_dec_forward_dense mode bit / arcvae_dec_backward_dense flags bit
 DEC_SPLIT3 = 512     # same places: three-piece (fp32-class) products
+DEC_NO_GPRE = 1024   # arcvae_dec_forward_dense mode bit: forward only, pre-activations not kept (fused GEMM + cell)
 WGRAD_BF16 = 128     # arcvae_enc_lstm_wgrad parts bit
 
 _vp = C.c_void_p

@@ -239,8 +239,11 @@ def _dec_gemm_bits(ws) -> int:
 
 
 def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: int = 0,
-                          temperature: float = 1.0) -> None:
-    """models/decoder.py:152-175 for all B*V (row, token) pairs."""
+                          temperature: float = 1.0, keep_gpre: bool = True) -> None:
+    """models/decoder.py:152-175 for all B*V (row, token) pairs.  keep_gpre=False (sampler, loss-only forward): the layers'
+    pre-activations are not kept, so a layer's GEMM and cell run as one kernel (csrc/gemm.hip gemm_cell_zero_kernel)."""
+    if not keep_gpre:
+        mode |= _lib.DEC_NO_GPRE
     wx, _k1 = _layer_ptrs(dec, d.L, "Wx")
     bs, _k2 = _layer_ptrs(dec, d.L, "bias")
     call("arcvae_dec_forward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
@@ -903,7 +906,7 @@ class StepEngine:
                 gate[0].wait(Gates.P, Gates.NS, Gates.STRIDE, 1, advance=gate[1])
             if backward:
                 self.dec.grad.zero_()
-            decoder_forward_dense(self.dec, ws, d)
+            decoder_forward_dense(self.dec, ws, d, keep_gpre=backward)
             decoder_chain(ws, d)
 
         def dec_bwd():

@@ -353,7 +353,8 @@ extern "C" int arcvae_dec_forward_dense(const float* emb, const float* const* Wx
         return ARCVAE_ERR_ARG;
     // the B*V-row products: throughput mode = bf16 operands; ARCVAE_DEC_SPLIT3 = three bf16 pieces, six products (fp32-class)
     const int BF = (mode & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : ((mode & ARCVAE_DEC_SPLIT3) ? ARCVAE_GEMM_SPLIT3 : 0);
-    mode &= ~(ARCVAE_DEC_BF16 | ARCVAE_DEC_SPLIT3);
+    const bool no_gpre = (mode & ARCVAE_DEC_NO_GPRE) != 0 && BF == 0;   // forward only: fuse GEMM + cell (exact-f32 path)
+    mode &= ~(ARCVAE_DEC_BF16 | ARCVAE_DEC_SPLIT3 | ARCVAE_DEC_NO_GPRE);
     if (mode == 1 && !(temperature > 0.f)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
         if (!Wx[l] || !bias[l]) return ARCVAE_ERR_ARG;
@@ -365,6 +366,10 @@ extern "C" int arcvae_dec_forward_dense(const float* emb, const float* const* Wx
                        bias[0], hact, B, V, E, C, H);
     for (int l = 1; l < L; ++l) {
         float* Gl = gpre + (long)(l - 1) * R * G;
+        if (no_gpre && R >= 4096 &&
+            arcvae_gemm_cell_zero((int)R, H, H, hact + (long)(l - 1) * R * H, H, Wx[l], H, bias[l], hact + (long)l * R * H,
+                                  stream) == ARCVAE_OK)
+            continue;                                      // (the pre-activations of this layer were never written)
         rc = arcvae_gemm_f32(0, 1, (int)R, G, H, hact + (long)(l - 1) * R * H, H, Wx[l], H, Gl, G, bias[l], BF,
                              stream);
         if (rc) return rc;

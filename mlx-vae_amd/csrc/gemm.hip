@@ -423,6 +423,121 @@ bool launch_bf16_tile_t(const GemmP& p, dim3 grid, bool ak, bool bk, hipStream_t
     return true;
 }
 
+// ---- forward-only decoder layer: G = A . W^T + b and the zero-state cell h = o * tanh(i * g) in ONE kernel ----------------
+// The sampler (BASELINE.json configs[4]) and the loss-only forward do not need the pre-activations G [B*V, 4H] afterwards,
+// yet wrote them (335 MB per bs-1024 batch) and read them back in cell_zero_fwd_kernel -- 130 us of a 740 us batch.  Same
+// tile kernel as gemm_tile_body<128, 128, A k-contiguous, W [4H, K]> (same loads, same k order of the exact-f32 MFMAs,
+// same "+ bias", same cell arithmetic as cell_zero_fwd_kernel: bit-identical h), except that the block's 128 output
+// columns are 32 units x (i, f, g, o): logical column c = 4 * unit + gate reads weight row gate * H + unit, so the gates
+// of a unit sit in four neighbouring lanes; the cell is evaluated in the accumulators' epilogue (two lane shifts per
+// value) and the [128 x 32] h tile leaves through LDS as full 128-byte row segments.
+struct CellGemmP {
+    const float* A;      // [M, K] (lda)
+    const float* W;      // [4H, K] (ldw), rows gate * H + unit
+    const float* bias;   // [4H]
+    float* Hout;         // [M, H]
+    int M, H, K, lda, ldw;
+};
+__global__ __launch_bounds__(256) void gemm_cell_zero_kernel(CellGemmP p) {
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MT = 2, NT = 2;
+    constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA_S + LDB_S)];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * BK * LDA_S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;      // n0: first LOGICAL column (4 * unit + gate)
+    const int G = 4 * p.H;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    TileLoader<BM, true, 4> la;
+    float4 vb[2];
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256, c = n0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < G && k < p.K) z = *reinterpret_cast<const float4*>(p.W + (long)((c & 3) * p.H + (c >> 2)) * p.ldw + k);
+            vb[i] = z;
+        }
+    };
+    auto store_b = [&](float* S) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256, r = idx >> 2, k = (idx & 3) * 4;
+            S[(k + 0) * LDB_S + r] = vb[i].x;
+            S[(k + 1) * LDB_S + r] = vb[i].y;
+            S[(k + 2) * LDB_S + r] = vb[i].z;
+            S[(k + 3) * LDB_S + r] = vb[i].w;
+        }
+    };
+    const int nk = (p.K + BK - 1) / BK;
+    la.load(p.A, p.lda, m0, p.M, 0, p.K, tid);
+    load_b(0);
+    la.store(As0, tid);
+    store_b(Bs0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            la.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+            load_b((kt + 1) * BK);
+        }
+        const float* as = As0 + cur * BK * LDA_S + (lane >> 5) * LDA_S + wm * WM + (lane & 31);
+        const float* bs = Bs0 + cur * BK * LDB_S + (lane >> 5) * LDB_S + wn * WN + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = as[kk * LDA_S + i * 32];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = bs[kk * LDB_S + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            la.store(As0 + (cur ^ 1) * BK * LDA_S, tid);
+            store_b(Bs0 + (cur ^ 1) * BK * LDB_S);
+        }
+        __syncthreads();
+    }
+    // ---- cell on the accumulators: lane's column c = 4 * unit + gate; gates g and o come from lanes + 2 and + 3
+    float* hs = smem;                                  // [128 rows][33]: the block's h tile (the operand tiles are dead)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cl = wn * WN + j * 32 + (lane & 31);       // logical column within the block tile
+            const int c = n0 + cl;
+            const float bv = c < G ? p.bias[(c & 3) * p.H + (c >> 2)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + bv;
+                const float gv = __shfl_down(v, 2), ov = __shfl_down(v, 3);
+                if ((lane & 3) == 0) {
+                    const float ig = sigmoidf_acc(v), gg = tanhf(gv), og = sigmoidf_acc(ov);
+                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    hs[row * 33 + (cl >> 2)] = og * tanhf(ig * gg);
+                }
+            }
+        }
+    __syncthreads();
+    const int u0 = n0 >> 2;                            // first unit of the block tile
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = q * 8 + (tid >> 5), ul = tid & 31;
+        if (m0 + row < p.M && u0 + ul < p.H) p.Hout[(long)(m0 + row) * p.H + u0 + ul] = hs[row * 33 + ul];
+    }
+}
+
 // Grouped launch: up to 8 same-layout problems in ONE launch (blockIdx.z walks [problem][k-slice]); used for the
 // per-layer weight-gradient GEMMs of a BPTT chunk, which are small, independent and otherwise each pay a launch.
 #define ARCVAE_GEMM_GROUP_MAX 8
@@ -1096,5 +1211,17 @@ int arcvae_wgrad_octet_group(int n, int M, int N, const int* K, const void* cons
     g.zoff[n] = ztot;
     for (int i = n; i < ARCVAE_OCT_GROUP_MAX; ++i) { g.p[i] = g.p[0]; g.zoff[i + 1] = ztot; }
     hipLaunchKernelGGL(wgrad_octet_kernel, dim3(ceil_div(N, 256), ceil_div(M, 256), ztot), dim3(256), 0, stream, g);
+    return arcvae_launch_status();
+}
+
+// h = zero_state_cell(A . W^T + bias) for a decoder layer whose pre-activations are not needed afterwards (gemm_cell_zero_kernel).
+// Internal (ops.h).  Returns ARCVAE_ERR_ARG when the operands do not allow the 16-byte loads (the caller then takes the two-launch path).
+int arcvae_gemm_cell_zero(int M, int H, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
+                          float* Hout, hipStream_t stream) {
+    if (M <= 0 || H <= 0 || K <= 0 || !A || !W || !bias || !Hout) return ARCVAE_ERR_ARG;
+    if ((K % 4) != 0 || (lda % 4) != 0 || (ldw % 4) != 0 || !aligned16(A) || !aligned16(W) || lda < K || ldw < K) return ARCVAE_ERR_ARG;
+    CellGemmP p;
+    p.A = A; p.W = W; p.bias = bias; p.Hout = Hout; p.M = M; p.H = H; p.K = K; p.lda = lda; p.ldw = ldw;
+    hipLaunchKernelGGL(gemm_cell_zero_kernel, dim3(ceil_div(4 * H, 128), ceil_div(M, 128)), dim3(256), 0, stream, p);
     return arcvae_launch_status();
 }

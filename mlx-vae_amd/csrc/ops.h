@@ -31,6 +31,11 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
 int arcvae_wgrad_octet_group(int n, int M, int N, const int* K, const void* const* A, const void* const* B,
                              float* const* C, int ldc, hipStream_t stream);
 
+// internal (C++ linkage): a forward-only decoder layer (GEMM + zero-state cell, no pre-activations kept), see gemm.hip
+int arcvae_gemm_cell_zero(int M, int H, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
+                          float* Hout, hipStream_t stream);
+#define ARCVAE_DEC_NO_GPRE 1024    /* arcvae_dec_forward_dense `mode` bit 10: forward only, the layers' pre-activations are not kept */
+
 // internal (C++ linkage): two skinny products in one launch, see gemm.hip
 int arcvae_gemm_skinny_pair(int transB, const int* M, const int* N, const int* K, const float* const* A, const int* lda,
                             const float* const* B, const int* ldb, float* const* C, const int* ldc,
