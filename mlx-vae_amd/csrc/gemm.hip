@@ -429,8 +429,8 @@ bool launch_bf16_tile_t(const GemmP& p, dim3 grid, bool ak, bool bk, hipStream_t
 // tile kernel as gemm_tile_body<128, 128, A k-contiguous, W [4H, K]> (same loads, same k order of the exact-f32 MFMAs,
 // same "+ bias", same cell arithmetic as cell_zero_fwd_kernel: bit-identical h), except that the block's 128 output
 // columns are 32 units x (i, f, g, o): logical column c = 4 * unit + gate reads weight row gate * H + unit, so the gates
-// of a unit sit in four neighbouring lanes; the cell is evaluated in the accumulators' epilogue (two lane shifts per
-// value) and the [128 x 32] h tile leaves through LDS as full 128-byte row segments.
+// of a unit are four neighbouring floats of a row of the pre-activation tile, which goes through LDS once: every thread then
+// evaluates 16 cells and h leaves in full 128-byte row segments.
 struct CellGemmP {
     const float* A;      // [M, K] (lda)
     const float* W;      // [4H, K] (ldw), rows gate * H + unit
@@ -441,7 +441,7 @@ struct CellGemmP {
 __global__ __launch_bounds__(256) void gemm_cell_zero_kernel(CellGemmP p) {
     constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MT = 2, NT = 2;
     constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA_S + LDB_S)];
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // max(operand tiles: 33.8 KB, pre-activation tile [128][129]: 66 KB)
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * BK * LDA_S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -509,8 +509,10 @@ __global__ __launch_bounds__(256) void gemm_cell_zero_kernel(CellGemmP p) {
         }
         __syncthreads();
     }
-    // ---- cell on the accumulators: lane's column c = 4 * unit + gate; gates g and o come from lanes + 2 and + 3
-    float* hs = smem;                                  // [128 rows][33]: the block's h tile (the operand tiles are dead)
+    // ---- the pre-activation tile (+ bias) goes to LDS [128 rows][129]; then every thread evaluates 16 cells -- its unit's
+    // gates i, g, o are three neighbouring floats of a row -- and writes h in full 128-byte row segments.  (Evaluating the
+    // cell on the accumulators needs the gates of a unit in ONE lane: with lane shifts only a quarter of the lanes work.)
+    float* gs = smem;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -520,13 +522,8 @@ __global__ __launch_bounds__(256) void gemm_cell_zero_kernel(CellGemmP p) {
             const float bv = c < G ? p.bias[(c & 3) * p.H + (c >> 2)] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][j][r] + bv;
-                const float gv = __shfl_down(v, 2), ov = __shfl_down(v, 3);
-                if ((lane & 3) == 0) {
-                    const float ig = sigmoidf_acc(v), gg = tanhf(gv), og = sigmoidf_acc(ov);
-                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    hs[row * 33 + (cl >> 2)] = og * tanhf(ig * gg);
-                }
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                gs[row * 129 + cl] = acc[i][j][r] + bv;
             }
         }
     __syncthreads();
@@ -534,7 +531,9 @@ __global__ __launch_bounds__(256) void gemm_cell_zero_kernel(CellGemmP p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int row = q * 8 + (tid >> 5), ul = tid & 31;
-        if (m0 + row < p.M && u0 + ul < p.H) p.Hout[(long)(m0 + row) * p.H + u0 + ul] = hs[row * 33 + ul];
+        const float* g4 = gs + row * 129 + 4 * ul;
+        const float ig = sigmoidf_acc(g4[0]), gg = tanhf(g4[2]), og = sigmoidf_acc(g4[3]);
+        if (m0 + row < p.M && u0 + ul < p.H) p.Hout[(long)(m0 + row) * p.H + u0 + ul] = og * tanhf(ig * gg);
     }
 }
 
@@ -1222,6 +1221,8 @@ int arcvae_gemm_cell_zero(int M, int H, int K, const float* A, int lda, const fl
     if ((K % 4) != 0 || (lda % 4) != 0 || (ldw % 4) != 0 || !aligned16(A) || !aligned16(W) || lda < K || ldw < K) return ARCVAE_ERR_ARG;
     CellGemmP p;
     p.A = A; p.W = W; p.bias = bias; p.Hout = Hout; p.M = M; p.H = H; p.K = K; p.lda = lda; p.ldw = ldw;
-    hipLaunchKernelGGL(gemm_cell_zero_kernel, dim3(ceil_div(4 * H, 128), ceil_div(M, 128)), dim3(256), 0, stream, p);
+    const int lds = (int)sizeof(float) * 128 * 129;   // >= the operand tiles' 2 * 16 * (132 + 132) floats
+    (void)hipFuncSetAttribute((const void*)gemm_cell_zero_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(gemm_cell_zero_kernel, dim3(ceil_div(4 * H, 128), ceil_div(M, 128)), dim3(256), lds, stream, p);
     return arcvae_launch_status();
 }
