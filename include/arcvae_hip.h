@@ -185,7 +185,8 @@ int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* W
  * bit 2 = dWx_l (l >= 1) and bias sums only, bit 3 = dWh_l only; bit 4 = exact-f32 tile GEMMs instead of the split-bf16
  * kernel; bit 5 = onehot_ws was written by arcvae_enc_prologue; bit 6 = the split-bf16 kernel's 128-row tile (the range
  * runs behind the sweep, no sweep block is resident); bit 8 = dtable_ws was zeroed ahead of the call (arcvae_enc_prologue:
- * the zero-fill launch in front of a `first` range is skipped); bit 7 = throughput mode (one bf16 product per GEMM step instead of
+ * the zero-fill launch in front of a `first` range is skipped); bit 10 = the per-layer GEMMs as three-piece tile GEMMs
+ * (ARCVAE_GEMM_SPLIT3: fp32-class accuracy, for the MFMA-bound regime beside the tiled sweeps); bit 7 = throughput mode (one bf16 product per GEMM step instead of
  * the six of the split form: not a parity path).  The token-table path is linear in dtable_ws, so a
  * time range may be given its own workspace and both `first` and `last` (zero, accumulate, fold) on any stream. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,

@@ -499,6 +499,12 @@ class EncoderBackwardPlan:
             # throughput mode: one bf16 product per GEMM step.  Not beside a persistent sweep: there the matrix pipe is
             # idle anyway and what counts is what fits on the sweep's SIMDs (measured at bs 64: 1.077 vs 1.03 ms)
             parts |= _lib.WGRAD_BF16
+        elif (not self.persistent and os.environ.get("ARCVAE_WGRAD_SPLIT3", "1") != "0"
+              and (_lib.load().arcvae_enc_lstm_tiled(ws.B, d.H, d.L) & 2)):
+            # MFMA-bound regime (the BPTT runs on the register-tiled kernels): the weight-gradient GEMMs as three-piece tile
+            # GEMMs -- 2.7x less matrix-pipe time at fp32-class accuracy (bs 2048: 22.3 -> 21.3 ms, configs[2]: 42.0 -> 40.9;
+            # at 128 / 256 rows, beside the persistent or 2x2 sweeps, the exact-f32 tile GEMM stays ahead: 1.705 vs 1.777, 3.24 vs 3.52)
+            parts |= 1024 | 16      # (| 16: the token-table one-hot GEMM keeps its exact-f32 tile form)
         elif not (self.persistent and ws.B <= 64):
             # The split-bf16 GEMM pays beside the one-row-group persistent sweep only (1.061 vs 1.083 ms at bs 64: its
             # 208 registers fit on a SIMD next to the sweep's 296, and it leaves the matrix pipe to the chain).  Beside

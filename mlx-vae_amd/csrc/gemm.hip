@@ -1136,7 +1136,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
         }
         return colsums_by_launch();
     }
-    if (allow_split) {   // bit 0 = split-bf16 kernel; bit 1 = its 128-row tile (no sweep resident); bit 2 = one bf16 product (throughput mode)
+    if (allow_split & 7) {   // bit 0 = split-bf16 kernel; bit 1 = its 128-row tile (no sweep resident); bit 2 = one bf16 product (throughput mode)
         bool ok = true;
         for (int i = 0; i < n; ++i) ok = ok && K[i] > 0 && split_tn_ok(M, N, A[i], lda, B[i], ldb);
         if (ok) {
@@ -1150,6 +1150,16 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
             if (rc || ride) return rc;
             return colsums_by_launch();
         }
+    }
+    if (allow_split & 8) {   // the three-piece tile GEMM (LDS-staged, ~130 registers): the MFMA-bound regime's choice -- 2.7x less
+        // matrix-pipe time than the exact-f32 tile GEMM beside the tiled sweeps (bs 2048: 22.3 -> 21.3 ms, configs[2]: 42.0 -> 40.9)
+        for (int i = 0; i < n; ++i) {
+            if (K[i] <= 0) continue;
+            const int rc = arcvae_gemm_f32(1, 0, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr,
+                                           ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_SPLIT3 | ARCVAE_GEMM_TILE64, stream);
+            if (rc) return rc;
+        }
+        return colsums_by_launch();
     }
     bool vec = (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0;
     for (int i = 0; i < n; ++i) vec = vec && aligned16(A[i]) && aligned16(B[i]) && K[i] > 0;

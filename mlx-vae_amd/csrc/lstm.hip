@@ -2602,7 +2602,7 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
             } else
             for (int i = 0; i < n; i += 8) {
                 rc = arcvae_gemm_tn_group_accum(n - i < 8 ? n - i : 8, G, H, Kg + i, Ag + i, G, Bg + i, H, Cg + i, H,
-                                                exact_f32 ? 0 : (1 | (wide ? 2 : 0) | (b16 ? 4 : 0)), Sg + i, stream);
+                                                (parts & 1024) ? 8 : (exact_f32 ? 0 : (1 | (wide ? 2 : 0) | (b16 ? 4 : 0))), Sg + i, stream);
                 if (rc) return rc;       // (bias gradients dbias_l += colsum(dG_l): inside the split kernel, else by launch)
             }
         }
