@@ -117,7 +117,7 @@ int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, con
 /* The same forward sweep as ONE persistent launch for the latency regime (H = 128, 256 or 384, L <= 4, B <= 256, weight
  * slices within LDS; arcvae_enc_lstm_persistent_ok says whether a shape qualifies): batch rows partitioned over the 8
  * XCDs, weights stationary in LDS, one flag-line barrier per XCD and tick.  No k-chunk-major h
- * copy is written.  sync_ws: 1024 u32 of scratch (forward: words [0, 272); the BPTT entry points: [512, 848); [500] = the
+ * copy is written.  sync_ws: 8192 u32 of scratch (forward: words [0, 272); the BPTT entry points: [512, 848); [500] = the
  * error word of both); sync_ws[500] != 0 afterwards = a block gave up waiting (sticky).
  * start_signal (optional): += 1 when the sweep starts.  The BPTT counterpart covers ticks [s_begin, s_end) of
  * arcvae_enc_lstm_backward's schedule per launch (L <= 2, ceil(B/8) * H/32 <= 64); a sweep uses it for all its
@@ -157,6 +157,12 @@ int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, co
  * reduce-scattered through the XCD's L2 (part_ws: RG*2*(2L-1)*8*32*32*64 floats, RG = 1 / 2 / 4 groups of 8 rows per
  * XCD for B <= 64 / 128 / 256).  Otherwise as arcvae_enc_lstm_backward_persistent. */
 int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
+/* 2 where the persistent sweeps run in their TWO-GROUP form (H = 256, L <= 2, 129 <= B <= 256: the 256-row shard of
+ * BASELINE.json configs[3]), else 1.  Two groups: 512 blocks, two per CU; every XCD's 17..32 rows are two independent
+ * recurrences of up to 16 rows with their own flag lines, and a CU's two blocks serve different groups, so that one group's
+ * exchange latency sits under the other's matrix work.  Such a step uses sync_ws words [1024, 4352)
+ * as well: re-arm 4352 words (arcvae_enc_prologue n_sync) instead of 848; part_ws as for RG = 4. */
+int arcvae_enc_lstm_persist_groups(int B, int H, int L);
 int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
                                            const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
                                            float* dxs, float* part_ws, unsigned* sync_ws, unsigned* start_signal, int B,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "arcvae_enc_lstm_bwd_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_rs_ok": [_i, _i, _i, _i],
+    "arcvae_enc_lstm_persist_groups": [_i, _i, _i],
     "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_backward_fused": [_pp, _pp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _vp,
                                        _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],

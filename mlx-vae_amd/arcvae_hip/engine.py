@@ -93,8 +93,11 @@ class Workspace:
         self.logvar = torch.empty(B, Z, **f32)
         self.z = torch.empty(B, Z, **f32)
         self.stats = torch.zeros(2 * Z + 4, **f32)
-        self.psync = torch.zeros(1024, **i32)    # scratch of the persistent sweeps: forward flags / role counters at [0, 272), the
-        #                                          BPTT sweeps' at [512, 848), [500] = the sticky error word of both
+        self.psync = torch.zeros(8192, **i32)    # scratch of the persistent sweeps: forward flags / role counters at [0, 272), the
+        #                                          BPTT sweeps' at [512, 848), [500] = the sticky error word of both; the
+        #                                          two-group forms' (129..256 rows per GPU) at [1024, 4352)
+        # words a step's prologue re-arms (arcvae_enc_lstm_persist_groups: two groups of 16 rows per XCD, two blocks per CU)
+        self.psync_words = 4352 if _lib.load().arcvae_enc_lstm_persist_groups(B, H, L) == 2 else 848
         self.bptt_rearmed = False                # the prologue of this step's forward has zeroed the BPTT sweep's words too
         # optional diagnostic stamps of the sweep launches / ticks (StepEngine.enable_trace), passed per call
         self.trace_fwd: Optional[torch.Tensor] = None
@@ -127,8 +130,8 @@ class Workspace:
             self.dtable1 = self.dtables[1]                    # the last chunk's token table, folded by the main stream itself
             self.tables_zeroed = False                        # this step's prologue has zeroed them (persistent forward path)
             self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)
-            if H == 256 and L <= 2 and B <= 256:  # partial sums in flight of the reduce-scatter BPTT sweep (12.6 MB per
-                rg = 1 if B <= 64 else (2 if B <= 128 else 4)   # group of 8 rows per XCD)
+            if _lib.load().arcvae_enc_lstm_bwd_rs_ok(B, T, H, L) == 1:   # partial sums in flight of the reduce-scatter BPTT sweep
+                rg = 1 if B <= 64 else (2 if B <= 128 else 4)   # (12.6 MB per group of 8 rows per XCD; only where that sweep runs)
                 self.ppart = torch.empty(rg * 2 * (2 * L - 1) * 8 * 32 * 32 * 64, **f32)
             self.dlogits = torch.empty(BV, V, **f32)
             self.ddh = torch.empty(2, BV, H, **f32)
@@ -195,7 +198,7 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         ws.tables_zeroed = tabs is not None
         ws.bptt_rearmed = True                   # consumed by the next EncoderBackwardPlan.sweep(chunk 0)
         call("arcvae_enc_prologue", ptr(ws.x), ptr(ws.x_tb), ptr(grad), C.c_long(grad.numel() if grad is not None else 0),
-             ptr(tabs), C.c_long(tabs.numel() if tabs is not None else 0), ptr(ws.psync), 848, 500, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
+             ptr(tabs), C.c_long(tabs.numel() if tabs is not None else 0), ptr(ws.psync), ws.psync_words, 500, ptr(ws.cond), ptr(enc.p("condition_fc.weight")), ptr(enc.p("condition_fc.bias")),
              ptr(ws.comb), ptr(ws.stats), 2 * d.Z + 4, ptr(ws.onehot) if (zero_grad and hasattr(ws, "onehot")) else C.c_void_p(0),
              d.V, B, T, d.H, d.C, s)
         comb_ready = 1

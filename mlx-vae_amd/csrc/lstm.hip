@@ -935,6 +935,12 @@ constexpr int PS_ERR = 500;                                  // sticky error wor
 constexpr int PS_BWD = 512;                                  // the BPTT sweeps' flags / role counters live at sync_ws + PS_BWD (their own
                                                              // words: both sweeps of a step can be re-armed by ONE zero fill ahead of the
                                                              // forward, arcvae_enc_prologue); the error word is shared (buffer: 1024 words)
+// Two-group form (NG = 2: up to 32 rows per XCD as two independent 16-row recurrences, two blocks per CU): its own words
+// behind the one-group regions -- forward flags [g][xcc][32] and role counters [g][xcc]; the same for the BPTT sweep with a
+// fresh set of role counters per chunk; and one table of per-CU arrival counters (8 XCDs x 256 CU keys) shared by every
+// launch of a step (a block's group = parity of its arrival on its CU; each launch adds two arrivals per CU).
+constexpr int PS2_FWD_FLAGS = 1024, PS2_FWD_CNT = 1536, PS2_BWD_FLAGS = 1552, PS2_BWD_CNT = 2064, PS2_CU = 2304;
+constexpr int PS2_WORDS = PS2_CU + 8 * 256;                  // 4352: what a two-group step re-arms (arcvae_enc_prologue)
 struct PersistArgs {
     const int32_t* x_tb;
     const float* table0;
@@ -945,10 +951,25 @@ struct PersistArgs {
     float* gseq;
     float* comb;                             // or null: [B,2H], its first H columns receive h_{T-1} of the top layer (heads' input)
     unsigned* sync;                          // PS_WORDS words, zeroed before the launch
+    unsigned* flags;                         // [NG][8 XCDs][32] published-tick words (one 128-B line per XCD and group)
+    unsigned* cnt;                           // [NG][8] role counters
+    unsigned* cucnt;                         // NG = 2: [8][256] arrivals per (XCD, CU key), or null (groups by arrival order)
     unsigned* start_signal;                  // or null: += 1 once, when the sweep starts
     unsigned long long* trace;               // or null: {start, end} per tick of block (xcc 0, role 0)
     int B, T, H, V, RX, prio;
+    int stagger;                             // two-group form: group 1 starts this many 10 ns units late (see ps_stagger)
 };
+
+// Two blocks of a CU that run the same tick loop fall into lockstep: both reach their matrix work together (and halve each
+// other's rate) and both wait for their flag lines together, so nothing hides behind anything.  Starting the second group
+// about half a tick late puts one group's exchange under the other's matrix work; the offset then holds by itself (a group
+// whose partner is in its wait phase finds the matrix pipe free and keeps its phase).
+__device__ __forceinline__ void ps_stagger(unsigned grp, int units) {
+    if (grp != 0 && units > 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)units) __builtin_amdgcn_s_sleep(8);
+    }
+}
 
 // "My stores are in the XCD's L2" -- what the flag protocol of the persistent kernels needs before a flag may be raised.
 // A workgroup-scope release fence is NOT that: on gfx942/gfx950 (not in tgsplit mode) the compiler emits no vmcnt wait
@@ -1003,6 +1024,46 @@ __device__ __forceinline__ s16x4_l pk4_bf16(f32x4 v) {
 
 constexpr bool persist_wreg(int NT, int LL) { return (2 * LL - 1) * (2 * NT) * NT <= 32; }
 
+// Diagnostic build only (-DARCVAE_PS_STAMPS, tools/tick_stamps.py; never the shipped library): eight stamps per tick of one
+// block (100 MHz wall clock) at trace[8 s + k] instead of the {start, end} pair at trace[2 s ..]: where a tick's time goes.
+#ifdef ARCVAE_PS_STAMPS
+#define PS_STAMP(k) do { if (tr) a.trace[8 * (long)s + (k)] = wall_clock64(); } while (0)
+#define PS_STAMP_START() PS_STAMP(1)
+#define PS_STAMP_END() PS_STAMP(7)
+#else
+#define PS_STAMP(k) do { } while (0)
+#define PS_STAMP_START() do { if (tr) a.trace[2 * s] = wall_clock64(); } while (0)
+#define PS_STAMP_END() do { if (tr) a.trace[2 * s + 1] = wall_clock64(); } while (0)
+#endif
+
+// Role of a block in a persistent sweep: (group, slot) on its XCD.  NG = 1: slot = arrival order on the XCD.  NG = 2 (two
+// blocks per CU, the XCD's rows as two independent 16-row recurrences): the two blocks of a CU should serve DIFFERENT groups
+// -- then one group's exchange latency (store acknowledgement, flag line, gather) sits under the other group's matrix work
+// on every CU, scheduled by the hardware between the SIMD's two waves.  Placement is speed only: any split of the XCD's 64
+// blocks into 32 + 32 is correct.  cucnt != null: arrivals per CU (key = the se / sh / cu fields of HW_ID), parity picks the
+// group and a full group sends the block to the other one; cucnt == null: the first 32 arrivals of the XCD take group 0.
+template <int NG>
+__device__ __forceinline__ void ps_take_role(unsigned* cnt, unsigned* cucnt, unsigned xcc, unsigned& grp, unsigned& role) {
+    if constexpr (NG == 1) {
+        grp = 0;
+        role = atomicAdd(cnt + (xcc & 7), 1u);
+    } else {
+        unsigned g, r;
+        if (cucnt) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            g = atomicAdd(cucnt + (xcc & 7) * 256 + ((hwid >> 8) & 0xff), 1u) & 1u;
+            r = atomicAdd(cnt + g * 8 + (xcc & 7), 1u);
+            if (r >= 32) { g ^= 1u; r = atomicAdd(cnt + g * 8 + (xcc & 7), 1u); }
+        } else {
+            g = 0;
+            r = atomicAdd(cnt + (xcc & 7), 1u);
+            if (r >= 32) { g = 1; r = atomicAdd(cnt + 8 + (xcc & 7), 1u); }
+        }
+        grp = g; role = r;
+    }
+}
+
 // MF = 1 (H = 256, at most 8 rows per XCD, L <= 2): the contraction on v_mfma_f32_4x4x1 blocks instead of 16x16x4 tiles.
 // With 8 rows a 16-row tile is half empty: 96 instructions of 32 cycles per wave and tick, 1.28 us of the tick, for
 // half that much useful work.  Blocks = 2 row groups x 8 column groups: ONE 4x4x1 instruction (8 cycles) is the rank-1
@@ -1010,9 +1071,13 @@ constexpr bool persist_wreg(int NT, int LL) { return (2 * LL - 1) * (2 * NT) * N
 // a lane loads 4 consecutive k of its row (block cg holds k = 4cg .. 4cg+3), and the instruction's A-broadcast
 // (cbsz = 3, abid = source block) hands one block's values to the 8 blocks of its row group, so the operand is loaded
 // once, without padded rows (2 16-byte loads per source instead of 4).  Weights are the B operand, 192 VGPRs.
-template <int NT, int LL, int RT, int MF = 0>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
-__global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
+// NG = 2: the two-group form -- 512 blocks, two per CU (the register budget of launch bounds (256, 2) and an LDS floor that
+// admits exactly two), every XCD's rows as two independent recurrences of up to 16 rows with their own flag lines
+// (ps_take_role); a block is the RT = 1 kernel on its group's rows.
+template <int NT, int LL, int RT, int MF = 0, int NG = 1>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
+__global__ __launch_bounds__(256, NG) void lstm_fwd_persist_kernel(PersistArgs a) {
     static_assert(MF == 0 || (NT == 2 && RT == 1 && LL <= 2), "4x4x1 form: H = 256, one row tile, L <= 2");
+    static_assert(NG == 1 || (RT == 1 && MF == 0), "two groups: one 16-row tile per group");
     // MF = 2 (throughput mode, ARCVAE_PERSIST_BF16): the same blocks on v_mfma_f32_4x4x4_16b_bf16 -- a lane's four consecutive
     // k (one 16-byte load of h, one float4 of its weight column) are ONE instruction instead of four: 48 instead of 192
     // matrix instructions per wave and tick, weights in 96 instead of 192 VGPRs (packed bf16), h and the weights rounded
@@ -1033,24 +1098,30 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
     float* wl = lds;                                 // [S][NCH][CW][16]   (LDS variant only)
     float* red = WREG ? lds : lds + S * NCH * CW * 16;   // [4 waves][LL][16*RT][CW]
     constexpr int RW = LL * 16 * RT * CW;            // floats per wave in red
-    __shared__ unsigned s_role, s_xcc, s_ok;
+    __shared__ unsigned s_role, s_xcc, s_ok, s_grp;
     arcvae_set_prio(a.prio);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = a.B, T = a.T, H = a.H, G = 4 * a.H, RX = a.RX;
+    const int B = a.B, T = a.T, H = a.H, G = 4 * a.H;
     if (tid == 0) {
         s_xcc = ps_xcc_id();
-        s_role = atomicAdd(a.sync + PS_CNT + (s_xcc & 7), 1u);
+        unsigned g_, r_;
+        ps_take_role<NG>(a.cnt, a.cucnt, s_xcc, g_, r_);
+        s_grp = g_; s_role = r_;
         s_ok = 1;
         if (blockIdx.x == 0 && a.start_signal)
             __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);   // wave-uniform (SGPRs)
+    const unsigned grp = NG == 1 ? 0u : __builtin_amdgcn_readfirstlane(s_grp);
     if (xcc >= 8 || role >= 32) {                    // no slot on this XCD: the others will time out and drain
         if (tid == 0) atomicAdd(a.sync + PS_ERR, 1u);
         return;
     }
-    const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
+    // rows of this block: the XCD's a.RX rows, or (two groups) the group's up to 16 of them (possibly none: the block then
+    // only keeps the protocol going -- its loads repeat row 0 of the XCD, its epilogue owns no pair)
+    const int RX = NG == 1 ? a.RX : max(0, min(16, a.RX - 16 * (int)grp));
+    const bool tr = a.trace && xcc == 0 && role == 0 && grp == 0 && tid == 0;
     // stationary weights: permuted rows [role*CW, +CW) of every source, read ONCE per launch straight from the row-major
     // parameters (no k-chunk-major copy, i.e. no re-layout launch in front of the sweep: round 2).  Permuted row rp of a
     // source = unit 4(rp >> 4) + (rp & 3), gate (rp >> 2) & 3: the 16 gate columns of 4 units are consecutive.
@@ -1096,11 +1167,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
         }
     }
     __syncthreads();
-    const int row0 = xcc * RX;
+    const int row0 = xcc * a.RX + 16 * (int)grp;
     int arow[RT];                                               // tile rows beyond this XCD's rows repeat the last one
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) arow[rt] = min(row0 + min(16 * rt + r, RX - 1), B - 1);
-    const int mrow = min(row0 + min(4 * rg + ij, RX - 1), B - 1);   // 4x4x1 form: the row of this lane's A values
+    for (int rt = 0; rt < RT; ++rt) arow[rt] = min(row0 + max(min(16 * rt + r, RX - 1), 0), B - 1);
+    const int mrow = min(row0 + max(min(4 * rg + ij, RX - 1), 0), B - 1);   // 4x4x1 form: the row of this lane's A values
     // epilogue ownership: layer el, pairs p = tl + i*TPL of the RX x UW (row, unit) pairs of this block
     const int el = min(tid / TPL, LL - 1), tl = tid - el * TPL;
     const bool eactive = tid < LL * TPL;
@@ -1108,10 +1179,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) cst[i] = 0.f;
     const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
-    unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
-    const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
+    unsigned* my_flag = a.flags + (grp * 8 + xcc) * 32 + role;
+    const unsigned* xflags = a.flags + (grp * 8 + xcc) * 32;
+    if constexpr (NG == 2) ps_stagger(grp, a.stagger);
 
     for (int s = 0; s < T + LL - 1; ++s) {
+        PS_STAMP(0);
         // The additive terms of this tick's gates (layer 0: token -> row of table0, a dependent pair of loads; else the
         // bias) do not depend on the previous tick: request them BEFORE waiting at the barrier.
         float pv[MAXP][4];
@@ -1155,7 +1228,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
             __syncthreads();
             if (!s_ok) return;
         }
-        if (tr) a.trace[2 * s] = wall_clock64();
+        PS_STAMP_START();
         if constexpr (MF != 0) {
             // ---- A operands: 4 consecutive k of my row per load; block cg of my row group holds k = 64w + 32m + 4cg + e
             f32x4 qx[LL][2], qh[LL][2];
@@ -1175,6 +1248,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                     qh[l][1] = ps_load_sc1_x4(rs, off + 128);
                 }
             }
+            PS_STAMP(2);
             // ---- rank-1 updates: for every k of my quarter, the A values of block (k >> 2) & 7 broadcast to its row group
 #pragma unroll
             for (int l = 0; l < LL; ++l) {
@@ -1233,6 +1307,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                 }
             }
         }
+        PS_STAMP(2);
         // ---- MFMA: pre-activations of my CW columns, K quarter of this wave, weights from LDS
 #pragma unroll
         for (int l = 0; l < LL; ++l) {
@@ -1271,7 +1346,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                         rp[(16 * rt + (lane >> 4) * 4 + reg) * CW + 16 * n + r] = acc[rt][n][reg];
         }
         }
+        PS_STAMP(3);
         __syncthreads();
+        PS_STAMP(4);
         // ---- cell update of my (row, unit) pairs; c stays in a register from tick to tick.  (Storing the saved gates
         // and c after the flag, under the next tick's barrier wait, was measured twice: no gain without the store wait
         // below, 0.5 % slower with it -- 1.083-1.085 vs 1.077-1.078 ms per step.)
@@ -1307,19 +1384,33 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistArgs a) {
                 a.cseq[el * lH + (long)te * sH + hb] = c;
             }
         }
+        PS_STAMP(5);
         ps_stores_in_l2();                                       // my h stores have reached the XCD's L2
+        PS_STAMP(6);
         __syncthreads();
         if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (tr) a.trace[2 * s + 1] = wall_clock64();
+        PS_STAMP_END();
     }
 }
 
-template <int NT, int LL, int RT, int MF = 0>
+template <int NT, int LL, int RT, int MF = 0, int NG = 1>
 void launch_persist(const PersistArgs& a, size_t lds, hipStream_t s) {
     // > 64 KB of dynamic LDS has to be allowed per kernel; set on every call (idempotent, no host state kept)
-    (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL, RT, MF>,
+    (void)hipFuncSetAttribute((const void*)lstm_fwd_persist_kernel<NT, LL, RT, MF, NG>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL, RT, MF>), dim3(256), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lstm_fwd_persist_kernel<NT, LL, RT, MF, NG>), dim3(256 * NG), dim3(256), lds, s, a);
+}
+// LDS allocation of a two-group block (ARCVAE_PERSIST2_LDS_KB, default 56): more than a third of a CU's 160 KB and at most
+// half of it, so that a CU admits exactly two of them
+inline size_t persist2_lds_bytes() {
+    int kb = arcvae_env_int("ARCVAE_PERSIST2_LDS_KB", 56);
+    kb = kb < 54 ? 54 : (kb > 80 ? 80 : kb);
+    return (size_t)kb * 1024;
+}
+// Two-group form of the persistent sweeps: H = 256, L <= 2, 17..32 rows per XCD (129..256 rows per GPU: the 256-row shard of
+// BASELINE.json configs[3]).  ARCVAE_PERSIST2 (bit 0 forward, bit 1 BPTT; 0 keeps the one-group kernels).
+inline bool persist_two_groups(int B, int H, int L, int which /* 1 forward sweep, 2 BPTT sweep, 3 either */) {
+    return (arcvae_env_int("ARCVAE_PERSIST2", 1) & which) != 0 && H == 256 && L >= 1 && L <= 2 && ceil_div(B, 8) > 16 && ceil_div(B, 8) <= 32;
 }
 inline int persist_row_tiles(int B) { return ceil_div(B, 8) > 16 ? 2 : 1; }
 // LDS allocation floor of the register-stationary persistent kernels (ARCVAE_PERSIST_LDS_KB, default 81 = more than half
@@ -1359,10 +1450,14 @@ struct PersistBwdArgs {
     float* dcs;               // [L][RS][B][H] ring
     float* dxs;               // [L][RS][B][H] ring
     unsigned* sync;           // PS_WORDS words; flags hold the global tick index, role counters per chunk launch
+    unsigned* flags;          // [NG][8 XCDs][32] published-tick words of this sweep
+    unsigned* cnt;            // [NG][8] role counters of THIS chunk launch
+    unsigned* cucnt;          // two-group form: [8][256] arrivals per (XCD, CU key), or null (ps_take_role)
     unsigned* err;            // the sticky error word (sync_ws + PS_ERR, shared with the forward sweep)
     unsigned* start_signal;
     unsigned long long* trace;
     int B, T, H, RX, RS, ld_dh_top, s_begin, s_end, cnt_off, prio;
+    int stagger;              // two-group form: group 1 starts this many 10 ns units late (ps_stagger)
 };
 
 template <int NT, int LL, int RT>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
@@ -1385,7 +1480,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
     const int B = a.B, T = a.T, H = a.H, G = 4 * a.H, RX = a.RX, RS = a.RS;
     if (tid == 0) {
         s_xcc = ps_xcc_id();
-        s_role = atomicAdd(a.sync + PS_CNT + a.cnt_off + (s_xcc & 7), 1u);
+        s_role = atomicAdd(a.cnt + (s_xcc & 7), 1u);
         s_ok = 1;
         if (blockIdx.x == 0 && a.start_signal)
             __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1423,8 +1518,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdArgs a)
     float dcst[MAXP];                                  // dc_{t+1} * f_{t+1} of my (layer, row, unit) pairs
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) dcst[i] = 0.f;
-    unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
-    const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
+    unsigned* my_flag = a.flags + xcc * 32 + role;
+    const unsigned* xflags = a.flags + xcc * 32;
 
     for (int s = a.s_begin; s < a.s_end; ++s) {
         // this tick's job of my slot
@@ -1591,6 +1686,7 @@ struct PersistRsArgs {
     float* dtable;            // [V,4H] token-table gradient workspace
     int V;
     int fw_dbg;               // timing experiments only (ARCVAE_FW_DEBUG): 1 no h loads, 2 no products, 4 no token table
+    int parmask;              // 1: the exchange buffers alternate with the tick's parity (0: timing experiments only -- a race)
 };
 
 // MF = 1 (registers only): the contraction on v_mfma_f32_4x4x1 (16 blocks of 4x4, K = 1) instead of 16x16x4.  An XCD owns
@@ -1615,11 +1711,18 @@ struct PersistRsArgs {
 // the 256-row shard of BASELINE.json configs[3]): a tick walks the groups -- products and partial stores of every
 // group, ONE store wait / flag / barrier, then gather and epilogue of every group -- so the per-tick exchange cost is
 // paid once for up to 32 rows.
-template <int LL, bool WR, int MF, bool FW = false, int RG = 1>   // WR: the weight slices live in registers, else in LDS
-__global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
+// MF = 0 with RG = 2 ("R16"): up to 16 rows as ONE 16x16x4 row tile -- the products of both 8-row halves in one pass (96
+// instructions per wave and tick, no padded rows), each half's partial sums into that half's exchange buffer, gather and
+// epilogue per half as in the RG = 2 walk.  NG = 2: the two-group form (see lstm_fwd_persist_kernel): 512 blocks, two per
+// CU, the XCD's up to 32 rows as two independent R16 recurrences with their own flag lines and exchange buffers.
+template <int LL, bool WR, int MF, bool FW = false, int RG = 1, int NG = 1>   // WR: the weight slices live in registers, else in LDS
+__global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
     static_assert(MF == 0 || WR, "the 4x4x1 form keeps its weights in registers");
     static_assert(!FW || MF == 1, "fused weight gradients: 4x4x1 form only");
-    static_assert(RG == 1 || (MF != 0 && !FW), "row groups: 4x4 forms, weight gradients by GEMM");
+    static_assert(RG == 1 || (MF != 0 && !FW) || (MF == 0 && (RG == 2 || RG == 4) && WR && !FW), "row groups: 4x4 forms or 16-row tiles; weight gradients by GEMM");
+    static_assert(NG == 1 || (MF == 0 && RG == 2), "two groups: the 16-row tile form");
+    constexpr bool R16 = MF == 0 && RG >= 2;          // the tile form: RG / 2 tiles of 16 rows (RG = 4: the XCD's 32 rows in one block)
+    constexpr int NRT = R16 ? RG / 2 : 1;
     // MF = 2 (throughput mode): the 4x4 blocks on v_mfma_f32_4x4x4_16b_bf16 -- four consecutive gate columns k per
     // instruction (48 instead of 192 per wave and tick), the weight rows packed to bf16 in 96 VGPRs, the local gate
     // gradients rounded to bf16 as they leave LDS; partial sums, exchange and cell epilogue stay f32.
@@ -1631,24 +1734,28 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
     float* dgl = wloc + (WR ? 0 : S * 256 * WS);      // [LL][16 rows][32 gate cols of mine]  (rows >= 8 stay zero)
     float* dxl = dgl + RG * DGL;                      // [RG][2][64]
     float* dtl = dxl + RG * 128;                           // FW: [V][33] token-table gradient of my 32 gate columns
-    __shared__ unsigned s_role, s_xcc, s_ok;
+    __shared__ unsigned s_role, s_xcc, s_ok, s_grp;
     arcvae_set_prio(a.prio);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = a.B, T = a.T, H = a.H, G = 4 * a.H, RX = a.RX, RS = a.RS;
+    const int B = a.B, T = a.T, H = a.H, G = 4 * a.H, RS = a.RS;
     if (tid == 0) {
         s_xcc = ps_xcc_id();
-        s_role = atomicAdd(a.sync + PS_CNT + a.cnt_off + (s_xcc & 7), 1u);
+        unsigned g_, r_;
+        ps_take_role<NG>(a.cnt, a.cucnt, s_xcc, g_, r_);
+        s_grp = g_; s_role = r_;
         s_ok = 1;
         if (blockIdx.x == 0 && a.start_signal)
             __hip_atomic_fetch_add(a.start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);   // wave-uniform (SGPRs)
+    const unsigned grp = NG == 1 ? 0u : __builtin_amdgcn_readfirstlane(s_grp);
     if (xcc >= 8 || role >= 32) {
         if (tid == 0) atomicAdd(a.err, 1u);
         return;
     }
-    const bool tr = a.trace && xcc == 0 && role == 0 && tid == 0;
+    const int RX = NG == 1 ? a.RX : max(0, min(16, a.RX - 16 * (int)grp));   // rows of this block (two groups: the group's)
+    const bool tr = a.trace && xcc == 0 && role == 0 && grp == 0 && tid == 0;
     // my 32 rows of every weight matrix as the MFMA's B operand: element (k, unit) = W[gate*H + 8*role + ul][unit] with
     // k = gate * 8 + ul.  Register variant: lane (r, q4) of wave w keeps k = 16c + q4 + e, unit = 64w + 16n + r.
     // LDS variant: transposed image [unit][k]; thread tid takes unit column tid of every row, the 32 loads of a source
@@ -1708,8 +1815,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
     if constexpr (FW)
         for (int i = tid; i < ar.V * 33; i += 256) dtl[i] = 0.f;   // row stride 33: rows of different tokens on different banks
     __syncthreads();
-    const int row0 = xcc * RX;
+    const int row0 = xcc * a.RX + 16 * (int)grp;
     const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
+    // the gate-gradient image of row `rw` of 8-row half g, layer l: one 16-row image (R16) or an image per half
+    auto dgl_row = [&](int g, int l, int rw) -> float* {
+        return R16 ? dgl + (l * 16 * NRT + 8 * g + rw) * 32 : dgl + g * DGL + (l * 16 + rw) * 32;
+    };
     // ---- fused weight gradients: sources q = 0: dWh_top (A = dG_top[t], B = h_top[t-1]); L = 2: q = 1: dWx_1 (dG_1[t],
     // h_0[t]), q = 2: dWh_0 (dG_0[t], h_0[t-1]).  32x32x2: A lane (c = lane & 31, k = lane >> 5) = dG[row 2kk + k][c],
     // B lane = h[row 2kk + k][64 wave + 32 tile + (lane & 31)]; D register g, lane: gate column (g&3) + 8(g>>2) + 4(lane>>5).
@@ -1781,11 +1892,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         hb[g] = (long)eb[g] * H + unit;
         dcst[g] = 0.f;
     }
-    unsigned* my_flag = a.sync + PS_FLAGS + xcc * 32 + role;
-    const unsigned* xflags = a.sync + PS_FLAGS + xcc * 32;
+    unsigned* my_flag = a.flags + (grp * 8 + xcc) * 32 + role;
+    const unsigned* xflags = a.flags + (grp * 8 + xcc) * 32;
     const long part_src = (long)8 * 32 * 32 * 64;     // floats per (parity, source)
+    float* const part_grp = ar.part + (long)grp * RG * 2 * S * part_src;   // two-group form: each group its own exchange buffers
+    if constexpr (NG == 2) ps_stagger(grp, a.stagger);
 
     for (int s = a.s_begin; s < a.s_end; ++s) {
+        PS_STAMP(0);
         const int skew = 2 * (LL - 1 - el);
         const int t = is_cell ? T - 1 - (s - skew) : T - 1 - (s + 1 - skew);
         const bool jact = slot < S && t >= 0 && t < T;
@@ -1819,16 +1933,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                 float v = 0.f;
                 if (tl_ + 1 >= 0 && tl_ + 1 < T && 8 * g + rw < RX && row0 + 8 * g + rw < B)
                     v = a.dG[l * lG + (long)(tl_ + 1) * sG + (long)(row0 + 8 * g + rw) * G + (k >> 3) * H + role * UW + (k & 7)];
-                dgl[g * DGL + (l * 16 + rw) * 32 + k] = v;
+                dgl_row(g, l, rw)[k] = v;
             }
             __syncthreads();
         }
         if (s > a.s_begin) wg_prepare(s - 1, 0, 2);   // FW (sources 0, 1; source 2 behind the flag store): operands of the weight-gradient products of the previous tick's gate gradients
-        if (tr) a.trace[2 * s] = wall_clock64();
+        PS_STAMP_START();
         // ---- partial products of the S slots from my local gate gradients; wave w covers units [64w, 64w + 64)
-        float* pbase = ar.part + (long)(s & 1) * S * part_src + (long)xcc * 32 * 32 * 64;   // group g: + g * 2 S part_src
+        float* pbase = part_grp + (long)(s & ar.parmask) * S * part_src + (long)xcc * 32 * 32 * 64;   // 8-row half g: + g * 2 S part_src
 #pragma unroll
-        for (int g = 0; g < RG; ++g)
+        for (int g = 0; g < (R16 ? 1 : RG); ++g)   // (R16: both halves in one pass of 16-row tiles)
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             const bool cellj = j < LL;
@@ -1880,38 +1994,53 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                         *reinterpret_cast<f32x4*>(pdst + (long)ch * 4 * 32 * 64) = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             } else {
-            f32x4 acc[4];
+            f32x4 acc[NRT][4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (actj) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(dgl + (ls * 16 + r) * 32 + 16 * c + q4);
+                    f32x4 av[NRT];
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt)
+                        av[rt] = *reinterpret_cast<const f32x4*>(dgl + (ls * 16 * NRT + 16 * rt + r) * 32 + 16 * c + q4);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
                         f32x4 w;
                         if constexpr (WR) w = wr[WR ? j : 0][WR ? n : 0][WR ? c : 0];
                         else w = *reinterpret_cast<const f32x4*>(wloc + (j * 256 + 64 * wave + 16 * n + r) * WS + 16 * c + q4);
                         // weights as the A operand: the product comes out transposed, lane (row r, units 4*(lane>>4)+reg)
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, av.x, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, av.y, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, av.z, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, av.w, acc[n], 0, 0, 0);
+#pragma unroll
+                        for (int rt = 0; rt < NRT; ++rt) {
+                            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, av[rt].x, acc[rt][n], 0, 0, 0);
+                            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, av[rt].y, acc[rt][n], 0, 0, 0);
+                            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, av[rt].z, acc[rt][n], 0, 0, 0);
+                            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, av[rt].w, acc[rt][n], 0, 0, 0);
+                        }
                     }
                 }
             }
-            // scatter: rows 0..7 (lanes with r < 8); a lane holds 4 consecutive units ju0.. of its row -> consumer
-            // ju0>>3, piece [row][ju0&7 ..]: one 16-byte store per tile (4 per slot instead of 16 dword stores)
-            if (r < 8) {
+            // scatter: rows 0..7 (lanes with r < 8; tile form: all 16 rows of every tile, each 8-row half into its own
+            // buffers); a lane holds 4 consecutive units ju0.. of its row -> consumer ju0>>3, piece [row][ju0&7 ..]: one
+            // 16-byte store per tile (4 per slot instead of 16 dword stores)
+            if (R16 || r < 8) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int ju0 = 64 * wave + 16 * n + q4;
-                    *reinterpret_cast<f32x4*>(pbase + j * part_src + ((long)(ju0 >> 3) * 32 + role) * 64 + r * 8 + (ju0 & 7)) = acc[n];
+                for (int rt = 0; rt < NRT; ++rt) {
+                    float* ph = pbase + (R16 ? (long)(2 * rt + (r >> 3)) * 2 * S * part_src : 0L);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int ju0 = 64 * wave + 16 * n + q4;
+                        *reinterpret_cast<f32x4*>(ph + j * part_src + ((long)(ju0 >> 3) * 32 + role) * 64 + (r & 7) * 8 + (ju0 & 7)) = acc[rt][n];
+                    }
                 }
             }
                     }
         }
+        PS_STAMP(2);
         ps_stores_in_l2();                                       // my partials have reached the XCD's L2
+        PS_STAMP(3);
         __syncthreads();
         if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // FW: the flags are travelling and the matrix pipe is idle: first part of the weight-gradient products
@@ -1934,6 +2063,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
         }
         __syncthreads();
         if (!s_ok) return;
+        PS_STAMP(4);
         // ---- gather: the 32 pieces of my (slot, row, unit), group by group, then that group's epilogue
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
@@ -1955,6 +2085,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
 #pragma unroll
                 for (int i = 0; i < 32; i += 4) dh += (v[i] + v[i + 1]) + (v[i + 2] + v[i + 3]);
             }
+#ifdef ARCVAE_PS_STAMPS
+            if (g == 0 && tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PS_STAMP(5); }
+#endif
         }
         float* dxg = dxl + g * 128;
         if (eact[g] && jact) {
@@ -1974,7 +2107,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
                 a.dcs[((long)el * RS + (t % RS)) * sH + hb[g]] = dcst[g];
                 float* dp = a.dG + el * lG + (long)t * sG + (long)eb[g] * G + unit;
                 dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
-                float* dl = dgl + g * DGL + (el * 16 + erow) * 32 + ul;   // my gate columns stay on the CU for the next tick
+                float* dl = dgl_row(g, el, erow) + ul;   // my gate columns stay on the CU for the next tick
                 dl[0] = d_i; dl[8] = d_f; dl[16] = d_g; dl[24] = d_o;
                 if constexpr (FW) {
                     if (el > 0) {                                    // bias gradient of the layers above 0: running sum
@@ -1987,8 +2120,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistRsArgs 
             }
         }
         }
+        PS_STAMP(6);
         __syncthreads();
-        if (tr) a.trace[2 * s + 1] = wall_clock64();
+        PS_STAMP_END();
     }
     if constexpr (FW) {
         // ---- the last tick's gate gradients, then everything this launch accumulated goes to the gradient buffers
@@ -2231,7 +2365,20 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
     for (int l = 0; l < L; ++l) { a.W[l] = Wh[l]; if (l > 0) a.W[L + l - 1] = Wx[l]; }
     for (int l = 0; l < ARCVAE_MAX_LAYERS; ++l) a.bias[l] = (l > 0 && l < L) ? bias[l] : nullptr;
     a.sync = sync_ws; a.start_signal = start_signal; a.trace = trace;
+    a.flags = sync_ws + PS_FLAGS; a.cnt = sync_ws + PS_CNT; a.cucnt = nullptr; a.stagger = 0;
     a.B = B; a.T = T; a.H = H; a.V = V; a.RX = ceil_div(B, 8); a.prio = arcvae_step_prio();
+    if (persist_two_groups(B, H, L, 1)) {   // two blocks per CU, two independent 16-row recurrences per XCD (the caller's
+        if (!(flags & 1)) {              // re-arm covers PS2_WORDS: arcvae_enc_prologue, or here)
+            rc = arcvae_zero(reinterpret_cast<float*>(sync_ws + PS2_FWD_FLAGS), 1, PS2_WORDS - PS2_FWD_FLAGS, PS2_WORDS - PS2_FWD_FLAGS, stream);
+            if (rc != ARCVAE_OK) return rc;
+        }
+        a.flags = sync_ws + PS2_FWD_FLAGS; a.cnt = sync_ws + PS2_FWD_CNT;
+        a.stagger = arcvae_env_int("ARCVAE_PERSIST2_STAGGER_FWD", 200);
+        a.cucnt = arcvae_env_int("ARCVAE_PERSIST2_ASSIGN", 1) != 0 ? sync_ws + PS2_CU : nullptr;
+        if (L == 1) launch_persist<2, 1, 1, 0, 2>(a, persist2_lds_bytes(), stream);
+        else launch_persist<2, 2, 1, 0, 2>(a, persist2_lds_bytes(), stream);
+        return arcvae_launch_status();
+    }
     const size_t lds = persist_lds_bytes(B, H, L);
     const int NT = H / 128;
     const int RTn = persist_row_tiles(B);
@@ -2279,6 +2426,7 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
     a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
     a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);   // chunk 0: words 256..263, then 272..
+    a.flags = a.sync + PS_FLAGS; a.cnt = a.sync + PS_CNT + a.cnt_off; a.cucnt = nullptr; a.stagger = 0;
     const size_t lds = persist_bwd_lds_bytes(B, H, L);
     const int NT = H / 128;
     const int RTn = persist_row_tiles(B);
@@ -2295,7 +2443,14 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
 extern "C" int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L) {
     // ARCVAE_RS_MAX_B
     return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && H == 256 && L >= 1 && L <= 2 && B >= 1 &&
-            B <= arcvae_env_int("ARCVAE_RS_MAX_B", 128) && B <= 256 && T >= 1) ? 1 : 0;
+            (B <= arcvae_env_int("ARCVAE_RS_MAX_B", 128) || persist_two_groups(B, H, L, 2)) && B <= 256 && T >= 1) ? 1 : 0;
+}
+
+// 2 if the persistent sweeps of this shape run in their two-group form (two blocks per CU, the XCD's 17..32 rows as two
+// independent 16-row recurrences: H = 256, L <= 2, 129 <= B <= 256), else 1.  A two-group step re-arms 4352 words of
+// sync_ws (arcvae_enc_prologue n_sync), a one-group step 848.
+extern "C" int arcvae_enc_lstm_persist_groups(int B, int H, int L) {
+    return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && B > 0 && persist_two_groups(B, H, L, 3)) ? 2 : 1;
 }
 
 // Reduce-scatter form of the persistent BPTT sweep (lstm_bwd_persist_rs_kernel): H = 256, L <= 2, B <= 256.
@@ -2314,13 +2469,16 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     if (H != 256 || L < 1 || L > 2 || B < 1 || B > 256 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
     const int rows_x = ceil_div(B, 8);                                  // rows per XCD
-    const int rgn = rows_x <= 8 ? 1 : (rows_x <= 16 ? 2 : 4);            // groups of 8 rows a tick walks
+    // two-group form (17..32 rows per XCD): two blocks per CU, each group an independent 16-row recurrence (R16 tile form)
+    const bool two = !fused && !(flags & ARCVAE_PERSIST_BF16) && persist_two_groups(B, H, L, 2);
+    const int rgn = two ? 2 : (rows_x <= 8 ? 1 : (rows_x <= 16 ? 2 : 4));   // groups of 8 rows a tick walks (per block)
     if (fused && rgn != 1) return ARCVAE_ERR_ARG;
     const int S = T + 2 * (L - 1);
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
     if (chunk_index == 0 && !(flags & 1)) {   // flags bit 0: the words were zeroed ahead of the step (arcvae_enc_prologue)
-        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws + PS_BWD), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+        const int rc = two ? arcvae_zero(reinterpret_cast<float*>(sync_ws + PS2_BWD_FLAGS), 1, PS2_CU - PS2_BWD_FLAGS, PS2_CU - PS2_BWD_FLAGS, stream)
+                           : arcvae_zero(reinterpret_cast<float*>(sync_ws + PS_BWD), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
         if (rc != ARCVAE_OK) return rc;
     }
     PersistRsArgs ar;
@@ -2330,11 +2488,18 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
     a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);
+    a.flags = a.sync + PS_FLAGS; a.cnt = a.sync + PS_CNT + a.cnt_off; a.cucnt = nullptr; a.stagger = 0;
+    if (two) {
+        a.stagger = arcvae_env_int("ARCVAE_PERSIST2_STAGGER_BWD", 200);
+        a.flags = sync_ws + PS2_BWD_FLAGS; a.cnt = sync_ws + PS2_BWD_CNT + 16 * chunk_index;
+        a.cucnt = arcvae_env_int("ARCVAE_PERSIST2_ASSIGN", 1) != 0 ? sync_ws + PS2_CU : nullptr;
+    }
     if (L == 2) { ar.W[0] = Wh[1]; ar.W[1] = Wh[0]; ar.W[2] = Wx[1]; }
     else { ar.W[0] = Wh[0]; ar.W[1] = Wh[0]; ar.W[2] = Wh[0]; }
     for (int i = 0; i < 2 * L - 1; ++i) if (!ar.W[i]) return ARCVAE_ERR_ARG;
     ar.part = part_ws;
     ar.fw_dbg = arcvae_env_int("ARCVAE_FW_DEBUG", 0);
+    ar.parmask = arcvae_env_int("ARCVAE_DEBUG_RS_PARMASK", 1) & 1;
     ar.hseq = nullptr; ar.x_tb = nullptr; ar.dW[0] = ar.dW[1] = ar.dW[2] = nullptr; ar.dbias1 = nullptr; ar.dtable = nullptr; ar.V = 0;
     if (fused) {
         if (!fused->hseq || !fused->x_tb || !fused->dWx || !fused->dWh || !fused->dbias || !fused->dtable || fused->V < 1 ||
@@ -2355,10 +2520,22 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     const bool wreg = arcvae_env_int("ARCVAE_RS_WREG", 1) != 0 || fused || rgn > 1;
     size_t lds = sizeof(float) * ((wreg ? 0 : (size_t)(2 * L - 1) * 256 * 36) + (size_t)rgn * (L * 16 * 32 + 128) + (fused ? 128 * 33 : 0));
     if (lds < persist_lds_floor()) lds = persist_lds_floor();
+    if (two) lds = persist2_lds_bytes();      // exactly two blocks per CU
     auto launch = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, stream, ar);
+        hipLaunchKernelGGL(kern, dim3(two ? 512 : 256), dim3(256), lds, stream, ar);
     };
+    if (two) {
+        if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 0, false, 2, 2>); else launch(lstm_bwd_persist_rs_kernel<2, true, 0, false, 2, 2>);
+        return arcvae_launch_status();
+    }
+    // The tile form for 9..32 rows per XCD (ARCVAE_RS_R16=0: the 4x4x1 blocks walking groups of 8 rows): all rows of the XCD
+    // in ONE pass of 16x16x4 tiles with full rows -- isolated tick 4.0 vs 5.4 us at 16 rows per XCD (bs 128)
+    if (rgn >= 2 && !(flags & ARCVAE_PERSIST_BF16) && arcvae_env_int("ARCVAE_RS_R16", 1) != 0) {
+        if (rgn == 2) { if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 0, false, 2>); else launch(lstm_bwd_persist_rs_kernel<2, true, 0, false, 2>); }
+        else { if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 0, false, 4>); else launch(lstm_bwd_persist_rs_kernel<2, true, 0, false, 4>); }
+        return arcvae_launch_status();
+    }
     // ARCVAE_RS_MFMA: 1 (default) = 4x4x1 blocks, 0 = 16x16x4 tiles (registers only; the LDS variant always uses 16x16x4)
     const bool mf = (wreg && arcvae_env_int("ARCVAE_RS_MFMA", 1) != 0) || fused || rgn > 1;
     if ((flags & ARCVAE_PERSIST_BF16) && mf && !fused && rgn <= 2) {   // throughput mode: the 4x4x4 bf16 form of the same blocks

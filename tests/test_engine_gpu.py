@@ -338,12 +338,17 @@ def test_persistent_sweeps_are_repeatable(H, L, B, T):
 
 
 @pytest.mark.parametrize("env", [{"ARCVAE_PERSIST": "0"}, {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "1"},
-                                 {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "0"}, {"ARCVAE_PERSIST": "1"}])
+                                 {"ARCVAE_PERSIST": "1", "ARCVAE_PERSIST_BWD": "0"}, {"ARCVAE_PERSIST": "1"},
+                                 # round 3: both sweeps in the two-group form (two blocks per CU); the one-group kernels for
+                                 # up to 32 rows per XCD in the 16-row tile form and in the 4x4x1 walk
+                                 {"ARCVAE_PERSIST2": "3"}, {"ARCVAE_PERSIST2": "0", "ARCVAE_RS_MAX_B": "256"},
+                                 {"ARCVAE_PERSIST2": "0", "ARCVAE_RS_MAX_B": "256", "ARCVAE_RS_R16": "0"}])
 @pytest.mark.parametrize("H,L,B,T,C", [(128, 2, 20, 9, 1), (128, 1, 33, 7, 2), (256, 2, 64, 12, 1), (384, 1, 9, 5, 1),
                                        (128, 2, 200, 6, 1), (256, 2, 250, 5, 1), (256, 2, 128, 6, 1),   # > 128 rows: two row tiles per XCD
                                        (128, 2, 3, 4, 1),                                                 # fewer rows than XCDs
                                        (256, 2, 37, 9, 2), (256, 1, 64, 5, 1),                            # reduce-scatter BPTT: ragged rows, one layer
-                                       (256, 2, 100, 7, 1), (256, 2, 70, 9, 1), (256, 1, 256, 5, 1), (256, 1, 100, 6, 1), (256, 1, 128, 4, 2)])     # ... in 2 groups of 8 rows per XCD (round 2)
+                                       (256, 2, 100, 7, 1), (256, 2, 70, 9, 1), (256, 1, 256, 5, 1), (256, 1, 100, 6, 1), (256, 1, 128, 4, 2),     # ... in 2 groups of 8 rows per XCD (round 2)
+                                       (256, 2, 256, 7, 1), (256, 2, 137, 6, 1), (256, 2, 200, 9, 2), (256, 1, 131, 5, 1)])   # round 3: the two-group form (two blocks per CU; ragged second groups)
 def test_persistent_sweeps_and_their_fallback(env, H, L, B, T, C, monkeypatch):
     """The persistent per-XCD sweeps (lstm_fwd_persist_kernel; BPTT: lstm_bwd_persist_rs_kernel by default at H = 256,
     lstm_bwd_persist_kernel with ARCVAE_PERSIST_BWD=1) and the per-step launches they replace, on shapes inside the persistent kernels' range: ragged row groups (B not a
