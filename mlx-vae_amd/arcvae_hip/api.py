@@ -24,6 +24,23 @@ def engine_for(encoder, decoder) -> StepEngine:
     return per_enc[key]
 
 
+def enable_data_parallel(encoder, decoder, group=None):
+    """Route loss_forward / value_and_grad of this (encoder, decoder) pair through arcvae_hip.dp.EngineDataParallel: every
+    call then takes the GLOBAL batch (identical on all ranks), works on this rank's rows and returns the global batch's
+    loss scalars; mu / logvar / z in the result are the LOCAL rows'.  torch.distributed must be initialised (one process
+    per GPU; backend nccl = RCCL).  Returns the driver (rank, world)."""
+    from .dp import EngineDataParallel
+    eng = engine_for(encoder, decoder)
+    if getattr(eng, "dp", None) is None:
+        eng.dp = EngineDataParallel(eng, group)
+    return eng.dp
+
+
+def data_parallel_of(encoder, decoder):
+    """The pair's data-parallel driver (enable_data_parallel), or None: single process."""
+    return getattr(engine_for(encoder, decoder), "dp", None)
+
+
 def draw_coins(T: int, ratio: float) -> np.ndarray:
     """models/decoder.py:180: one np.random.rand() per timestep from the GLOBAL legacy stream, drawn even
     when ratio == 0.0 (validation)."""
@@ -54,6 +71,10 @@ def loss_forward(encoder, decoder, x, conditions, eps=None, coins=None, teacher_
         coins = draw_coins(T, teacher_forcing_ratio)
     if eps is None:
         eps = draw_eps(B, encoder.latent_dim, encoder.store.device)
+    dp = getattr(eng, "dp", None)
+    if dp is not None:       # N ranks: this rank's rows, one all-reduce of the partial sums, the global batch's scalars
+        x, conditions = _dev_batch(eng, x, conditions)
+        return _as_dict(eng, dp.forward_loss(x, conditions, _local_eps(dp, eps, B), coins, **hyper), clone=True)
     eng.forward_loss(x, conditions, eps, coins, **hyper)
     return _as_dict(eng, eng.workspace(B, T, train=False), clone=True)
 
@@ -68,6 +89,28 @@ def value_and_grad(encoder, decoder, x, conditions, eps=None, coins=None, teache
         coins = draw_coins(T, teacher_forcing_ratio)
     if eps is None:
         eps = draw_eps(B, encoder.latent_dim, encoder.store.device)
+    dp = getattr(eng, "dp", None)
+    if dp is not None:
+        if lr is None:
+            raise ValueError("the data-parallel step applies both Adam updates: pass lr")
+        x, conditions = _dev_batch(eng, x, conditions)
+        ws = dp.train_step(x, conditions, _local_eps(dp, eps, B), coins, lr, **hyper)
+        return _as_dict(eng, ws, clone=False, status=True), (encoder.gradients(), decoder.gradients())
     eng.train_step(x, conditions, eps, coins, lr=lr if lr is not None else 0.0, update=lr is not None, **hyper)
     ws = eng.workspace(B, T, train=True)
     return _as_dict(eng, ws, clone=False, status=True), (encoder.gradients(), decoder.gradients())
+
+
+def _dev_batch(eng: StepEngine, x, conditions):
+    """Device-resident, contiguous global batch in the workspace's dtypes (what EngineDataParallel slices rows from)."""
+    from .module import as_f32, as_tokens
+    xt = as_tokens(x, eng.device)
+    return xt, as_f32(conditions, eng.device).reshape(xt.shape[0], eng.d.C)
+
+
+def _local_eps(dp, eps, B: int):
+    """eps of the GLOBAL batch ([B, Z], sliced by the driver) -- an own draw per rank when none was injected."""
+    if eps is None:
+        return draw_eps(B, dp.eng.d.Z, dp.eng.device)
+    from .module import as_f32
+    return as_f32(eps, dp.eng.device)

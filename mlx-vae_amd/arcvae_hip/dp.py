@@ -44,10 +44,6 @@ class StepOps(Protocol):
     def forward_local(self) -> None: ...      # fills self.stats with this rank's partial sums; starts the decoder
     def backward_local(self) -> None: ...     # self.stats now holds GLOBAL sums; fills the encoder's gradients
     def early_buckets(self) -> List[torch.Tensor]: ...  # gradients that do not depend on the stats seam (decoder)
-    def early_done(self) -> None:
-        if self.gated:
-            self._dec_adam_gated()                   # decoder gradients are GLOBAL: its Adam update rides on side too
-
     def late_buckets(self) -> List[torch.Tensor]: ...   # gradients ready after backward_local
     def early_context(self) -> ContextManager: ...      # stream context the early reduces are issued from
     def recon_local(self) -> None: ...        # fills the CE sum (inside early_context)
@@ -74,7 +70,10 @@ class DataParallelStep:
         self.force = os.environ.get("ARCVAE_DP_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
         self.early_group = early_group
         if early_group is None and dist.is_initialized() and (self.world > 1 or self.force):
-            self.early_group = dist.new_group()         # all ranks, same backend as the default group
+            # the same ranks as `group` (a subgroup's second communicator must not span the default group: its ranks
+            # outside `group` would never make this collective call), same backend
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self.early_group = dist.new_group(ranks=ranks)
         warm = getattr(ops, "warm_up", None)
         if warm is not None and self.early_group is not None:
             warm(self.early_group)                      # set the second communicator up before any gate can wait behind it
@@ -276,3 +275,105 @@ class EngineOps:
             return
         torch.cuda.current_stream().wait_stream(self.comm)
         self.eng.enqueue_finish(self.ws, self.lr, True, self.run)
+
+
+# ---- the trainer's two calls under data parallelism ------------------------------------------------------------------
+def shard_bounds(n_rows: int, rank: int, world: int):
+    """Rows [lo, hi) of a batch of n_rows that rank `rank` of `world` processes: contiguous, sizes differ by at most
+    one (the ragged last batch of an epoch), every row owned exactly once."""
+    return n_rows * rank // world, n_rows * (rank + 1) // world
+
+
+def shard_plan(n_rows: int, rank: int, world: int):
+    """(lo, hi, replicated): this rank's rows of a batch.  A batch with fewer rows than ranks (the ragged tail of an epoch
+    can be that small) is REPLICATED: every rank works on all of its rows, without collectives, and the results are those of
+    the single process by construction (training: rank 0's updated weights and optimizer state are then broadcast, so the
+    ranks stay bit-identical whatever the reduction order inside their kernels)."""
+    if n_rows < world:
+        return 0, n_rows, True
+    lo, hi = shard_bounds(n_rows, rank, world)
+    return lo, hi, False
+
+
+class EngineDataParallel:
+    """N ranks x row shard == one process x global batch for the two calls the trainer makes (reference trainer.py:242-333
+    is single-process; this layer is defined by that equivalence).  Every rank holds the same weights, the same dataset
+    order (np.random.shuffle on the same seeded global stream) and the same teacher-forcing coins; a call receives the
+    GLOBAL batch, takes this rank's rows (`shard_bounds`) and
+
+      train_step   : DataParallelStep(EngineOps) -- stats seam + two gradient buckets over RCCL, both Adam updates; the
+                     loss scalars every rank reads are the GLOBAL batch's (they are evaluated from the all-reduced sums);
+      forward_loss : the loss forward on the local rows, ONE all-reduce of the 2Z+4 partial sums (latent sums, KL sums, row
+                     count, CE sum), then the scalars of the global batch on every rank (validation / logging passes).
+
+    One driver (captured segments, bucket views) per (local rows, T, global rows, lr); the second communicator is created
+    once and shared."""
+
+    def __init__(self, engine, group: Optional[dist.ProcessGroup] = None):
+        if not dist.is_initialized():
+            raise RuntimeError("EngineDataParallel needs an initialised torch.distributed process group")
+        self.eng, self.group = engine, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._drivers = {}
+        self._early_group = None
+
+    def bounds(self, n_rows: int):
+        return shard_plan(n_rows, self.rank, self.world)
+
+    def _broadcast_state(self) -> None:
+        """Rank 0's parameters and Adam state to every rank (after a replicated step)."""
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        for st in (self.eng.enc, self.eng.dec):
+            for buf in (st.flat, st.adam_m, st.adam_v):
+                dist.broadcast(buf, src=src, group=self.group)
+
+    def _load(self, ws, x, cond, eps, coins, lo, hi):
+        self.eng.load_inputs(ws, x[lo:hi], cond[lo:hi], None if eps is None else eps[lo:hi], coins)
+
+    def train_step(self, x, cond, eps, coins, lr: float, **hyper):
+        """Loss, gradients and both Adam updates for the GLOBAL batch (x, cond, eps: all rows, identical on every rank;
+        eps may also be this rank's own draw of the right shape: no loss value depends on it, Q2).  Returns the local
+        workspace: ws.scalars are the global batch's loss scalars."""
+        eng = self.eng
+        n, T = int(x.shape[0]), int(x.shape[1])
+        lo, hi, replicated = self.bounds(n)
+        if replicated:       # fewer rows than ranks: the single-process step on every rank, then rank 0's state everywhere
+            eng.train_step(x, cond, eps, coins, lr=lr, update=True, **hyper)
+            self._broadcast_state()
+            return eng.workspace(n, T, train=True)
+        ws = eng.workspace(hi - lo, T, train=True)
+        eng.set_hyper(ws, **hyper)
+        self._load(ws, x, cond, eps, coins, lo, hi)
+        key = (hi - lo, T, n, float(lr), float(eng.hyper_host["free_bits"]))
+        drv = self._drivers.get(key)
+        if drv is None:
+            ops = EngineOps(eng, ws, lr, n, use_graph=(eng.mode != "eager"))
+            drv = DataParallelStep(ops, self.group, early_group=self._early_group)
+            self._early_group = drv.early_group
+            self._drivers[key] = drv
+        drv.step()
+        return ws
+
+    def forward_loss(self, x, cond, eps, coins, **hyper):
+        """complete_vae_loss forward of the GLOBAL batch: local rows -> partial sums -> one all-reduce -> scalars."""
+        from .engine import latent_loss
+        eng = self.eng
+        n, T = int(x.shape[0]), int(x.shape[1])
+        lo, hi, replicated = self.bounds(n)
+        if replicated:
+            eng.forward_loss(x, cond, eps, coins, **hyper)
+            return eng.workspace(n, T, train=False)
+        ws = eng.workspace(hi - lo, T, train=False)
+        eng.set_hyper(ws, **hyper)
+        self._load(ws, x, cond, eps, coins, lo, hi)
+        main = torch.cuda.current_stream()
+        eng.side.wait_stream(main)
+        eng.enqueue_encoder_forward(ws, backward=False)      # this rank's partial latent sums in ws.stats
+        eng.enqueue_decoder(ws, n, backward=False, wait_current=False)
+        eng.enqueue_recon(ws)                                # + its CE row sums (waits for the decoder's walk)
+        dist.all_reduce(ws.stats, op=dist.ReduceOp.SUM, group=self.group)
+        latent_loss(ws, eng.d, float(eng.hyper_host["free_bits"]), False)
+        ga, gb = eng.guards(ws)
+        call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), eng.d.Z, ws.T, ga, gb, stream_ptr())
+        main.wait_stream(eng.side)
+        return ws

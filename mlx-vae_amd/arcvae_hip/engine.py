@@ -765,6 +765,7 @@ class StepEngine:
         # device-side gates instead of event waits in the single-process step (class Gates); ARCVAE_GATES=0: events
         self.gates: Optional[Gates] = Gates(self.device) if os.environ.get("ARCVAE_GATES", "1") != "0" else None
         self._gating: Dict[int, bool] = {}
+        self.dp = None     # arcvae_hip.dp.EngineDataParallel once api.enable_data_parallel was called for this pair
 
     # `use_graph` is the older boolean switch: True -> captured segments, False -> eager launches
     @property
@@ -800,8 +801,11 @@ class StepEngine:
     def guards(self, ws: Workspace):
         """The two device error words of a step: the gates' ERR counter and the persistent sweeps' sticky error word.
         The loss-finalize and Adam kernels read them ON THE DEVICE: a step whose stream order was lost gets NaN loss
-        scalars (+ scalars[15] = 1) and NO parameter update -- the weights survive until the host notices
-        (`step_status`, read by the trainer with its per-batch loss; `check_gates`)."""
+        scalars (+ scalars[15] = 1) and its ENCODER update is skipped.  The decoder's update rides at the end of the
+        decoder's own segment, ~1 ms before the sweeps finish: it is skipped when the words are already set by then (a
+        failure of an earlier step, a forward sweep that gave up), but a word raised later in the same step finds it
+        applied -- the two modules are then one update apart, which is why the trainer stops at that batch and refuses
+        to checkpoint (`step_status`, read with the per-batch loss; `check_gates`)."""
         ga = self.gates.word(Gates.ERR) if self.gates is not None else C.c_void_p(0)
         return ga, C.c_void_p(ws.psync.data_ptr() + 4 * 500)
 

@@ -5,7 +5,14 @@ Drop-in for the reference's `python train.py ...` (train.py:17-255): identical f
 argparse defaults (note Q17: these are the ARGPARSE defaults, not the README's), identical seed,
 80/10/10 split, checkpoint clearing / `--resume` behaviour, history keys and output files.
 Additive flags: --device, --synthetic N (generate a SELFIES-shaped dataset when the JSON is absent;
-the reference's dataset blob is not distributed), --no_progress.
+the reference's dataset blob is not distributed), --no_progress, --precision, --world_size / --dist_backend.
+
+Data parallel over the GPUs of one node (the reference is single-process):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29544 \
+           train.py --batch_size 2048 ...
+one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher); --batch_size stays the GLOBAL batch, every rank
+steps its row shard, loss statistics and gradients are all-reduced over RCCL (arcvae_hip/dp.py), and the history, the
+checkpoints and the plots (written by rank 0) are those of the single-process run on the same batches.
 """
 from __future__ import annotations
 
@@ -55,6 +62,12 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--device", type=str, default=None, help="HIP device, e.g. cuda:0 (extension)")
     ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic SELFIES-shaped rows (extension)")
     ap.add_argument("--no_progress", action="store_true", help="disable progress bars (extension)")
+    ap.add_argument("--world_size", type=int, default=None,
+                    help="number of data-parallel ranks (extension; default: WORLD_SIZE of the launcher, else 1).  Start the "
+                         "ranks with `python -m torch.distributed.run --nproc-per-node N train.py ...`")
+    ap.add_argument("--dist_backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend (extension): nccl = RCCL over xGMI, one rank per GPU; gloo carries "
+                         "device tensors through the host (several ranks on one GPU: tests)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=None,
                     help="fp32: the parity path (default); bf16: throughput mode -- matrix products on bf16 operands with "
                          "f32 accumulation, parameters and optimizer state in f32 (extension; ARCVAE_PRECISION does the same)")
@@ -72,15 +85,44 @@ def synthetic_dataset(n: int, vocab: int, max_length: int = 128):
     return {"molecules": mols, "tokenized_sequences": seqs, "max_length": max_length}
 
 
+def init_data_parallel(args):
+    """(rank, world): joins the launcher's process group when WORLD_SIZE / --world_size > 1 (one process per GPU; the
+    device defaults to cuda:LOCAL_RANK), else (0, 1) without touching torch.distributed."""
+    world = args.world_size if args.world_size is not None else int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) != world:
+        raise SystemExit(f"--world_size {world}: start the ranks with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {world} --master-addr 127.0.0.1 --master-port 29544 train.py ...`")
+    import torch
+    import torch.distributed as dist
+    rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+    if args.device is None:
+        args.device = f"cuda:{local_rank}"
+    torch.cuda.set_device(torch.device(args.device))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
+    kw = dict(device_id=torch.device(args.device)) if args.dist_backend == "nccl" else {}
+    dist.init_process_group(args.dist_backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.precision:                      # read when the step engine of the model is created (arcvae_hip/engine.py)
         os.environ["ARCVAE_PRECISION"] = args.precision
+    rank, world = init_data_parallel(args)
+    import builtins
+    print = builtins.print if rank == 0 else (lambda *a, **k: None)   # noqa: A001  N ranks run the same flow; rank 0 reports
+    args.no_progress = args.no_progress or rank != 0
     from mlx_data.dataloader import MoleculeDataset
     from models.vae import ARCVAE
     from trainer import ARCVAETrainerWithLoss
 
     print("=" * 80 + "\nAR-CVAE Training (MI355X)\n" + "=" * 80)
+    if world > 1:
+        print(f"  Data parallel: {world} ranks ({args.dist_backend}), global batch {args.batch_size}")
     print(f"  Dataset: {args.data if not args.synthetic else f'synthetic x{args.synthetic}'}")
     print(f"  Model: embedding={args.embedding_dim}, hidden={args.hidden_dim}, latent={args.latent_dim}")
     print(f"  Training: epochs={args.epochs}, batch_size={args.batch_size}, lr={args.learning_rate}")
@@ -119,16 +161,27 @@ def main(argv=None):
         if not ckpt.exists():
             raise FileNotFoundError(f"Checkpoint not found: {ckpt}")
         print(f"\nResuming from checkpoint: {ckpt}")
-    elif checkpoint_dir.exists():
+    elif checkpoint_dir.exists() and rank == 0:
         for f in checkpoint_dir.glob("*.npz"):
             f.unlink()
         plot = checkpoint_dir / "training_history.png"
         if plot.exists():
             plot.unlink()
 
+    generator = None
+    if world > 1:       # identical initial weights on every rank: rank 0's seed (the reference's init is unseeded MLX RNG)
+        import torch
+        import torch.distributed as dist
+        seed = torch.tensor([torch.seed() % (2 ** 31)], dtype=torch.int64,
+                            device=args.device if args.dist_backend == "nccl" else "cpu")
+        dist.broadcast(seed, src=0)
+        generator = torch.Generator().manual_seed(int(seed.item()))
     vae = ARCVAE(vocab_size=args.vocab_size, embedding_dim=args.embedding_dim, hidden_dim=args.hidden_dim,
                  latent_dim=args.latent_dim, num_conditions=args.num_conditions, num_layers=args.num_layers,
-                 dropout=args.dropout, device=args.device)
+                 dropout=args.dropout, device=args.device, generator=generator)
+    if world > 1:
+        from arcvae_hip import api
+        api.enable_data_parallel(vae.encoder, vae.decoder)
     trainer = ARCVAETrainerWithLoss(
         encoder=vae.encoder, decoder=vae.decoder, property_predictor=None, dataset=train_dataset,
         batch_size=args.batch_size, learning_rate=args.learning_rate, beta_start=args.beta_start,
@@ -160,6 +213,11 @@ def main(argv=None):
                   f"Val Loss: {metrics['val_loss']:.4f}, Beta: {metrics['beta']:.4f}")
     trainer.plot_history(save_path=f"{args.checkpoint_dir}/training_history.png")
     print("\nTraining complete")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return trainer
 
 
 if __name__ == "__main__":

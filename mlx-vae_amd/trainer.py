@@ -11,6 +11,13 @@ nothing, so `grad_clip` never changes a gradient); a "loss explosion" only drops
 the running mean, the update has already been applied (Q15); every 25th batch a second forward is
 run for logging with post-update weights and T more coins (Q16).
 Checkpoints: same file names, but a flat non-pickle .npz keyed by the parameter names (Q21).
+
+Data parallelism (the reference is single-process): under `torch.distributed` (train.py started by
+`python -m torch.distributed.run`, one process per GPU) every rank runs THIS epoch flow on the same dataset order and the
+same coins (one seeded NumPy stream), every batch is the GLOBAL batch, and the step / the loss forwards work on the
+rank's row shard with the stats seam and the gradient buckets all-reduced over RCCL (arcvae_hip.dp.EngineDataParallel,
+enabled by `api.enable_data_parallel`).  The loss scalars every rank logs are the global batch's, so the history is the
+single-process history; rank 0 alone prints and writes checkpoints / history / plots.
 """
 from __future__ import annotations
 
@@ -50,11 +57,36 @@ class ARCVAETrainerWithLoss:
         self.progress = progress
         self.persist_best_val = False  # Q21: the reference never writes best_val_loss
         self.best_val_loss = float("inf")
-        self.engine = api.engine_for(encoder, decoder)
+        self.engine = self._make_engine(encoder, decoder)
+        self.rank, self.world = self._rank_world()
+        if self.rank != 0:
+            self.progress = False
+        # set when a step reported a lost stream order: the encoder's update was skipped on the device, but the decoder's
+        # (applied ~1 ms earlier, at the end of its own segment) may already be in -- the two modules can be one step
+        # apart, so this state is never checkpointed
+        self.poisoned = False
         self.history = {k: [] for k in (
             "epoch", "train_loss", "train_recon", "train_kl", "train_collapse", "train_prop", "val_loss",
             "val_recon", "val_kl", "val_collapse", "val_prop", "beta", "teacher_forcing", "learning_rate",
             "mutual_info")}
+
+    # ---- the three calls into the step engine (tests drive the same epoch flow with oracle-backed ones) ----------
+    def _make_engine(self, encoder, decoder):
+        return api.engine_for(encoder, decoder)
+
+    def _rank_world(self) -> Tuple[int, int]:
+        dp = api.data_parallel_of(self.encoder, self.decoder)
+        return (dp.rank, dp.world) if dp is not None else (0, 1)
+
+    def _train_step(self, molecules, conditions, teacher_forcing_ratio: float, hyper: Dict[str, float]):
+        """loss + grads + (no-op clip, Q6) + both Adam updates: one captured step (N ranks: arcvae_hip.dp).  Returns
+        [total_loss, step status] of the GLOBAL batch as one tensor: read together, one host sync per batch."""
+        out, _ = api.value_and_grad(self.encoder, self.decoder, molecules, conditions,
+                                    teacher_forcing_ratio=teacher_forcing_ratio, lr=self.learning_rate, **hyper)
+        return out["loss_and_status"]
+
+    def _encode(self, molecules, conditions):
+        return self.encoder(molecules, conditions)
 
     # ---- schedules (trainer.py:102-114) ------------------------------------------------------
     def compute_beta(self, epoch: int) -> float:
@@ -106,7 +138,8 @@ class ARCVAETrainerWithLoss:
         beta = self.compute_beta(epoch)
         tf = self.compute_teacher_forcing_ratio(epoch, total_epochs)
         self.last_train_metrics = self._train_epoch_batches(beta, tf)
-        self.engine.check_gates()  # a device-side gate that expired would mean the step's streams lost their order
+        if self.engine is not None:
+            self.engine.check_gates()  # a device-side gate that expired would mean the step's streams lost their order
         true_train = self._compute_true_train_loss(epoch, num_batches=20)
         val = self._validate(val_dataset, beta) if val_dataset is not None else dict(
             loss=0.0, recon=0.0, kl=0.0, collapse=0.0, prop=0.0)
@@ -130,10 +163,7 @@ class ARCVAETrainerWithLoss:
         if self.progress:
             it = tqdm(it, total=len(self.dataset) // self.batch_size, desc="Training batches")
         for batch_idx, (molecules, conditions) in enumerate(it):
-            # loss + grads + (no-op clip, Q6) + both Adam updates: one captured step
-            out, _ = api.value_and_grad(self.encoder, self.decoder, molecules, conditions,
-                                        teacher_forcing_ratio=teacher_forcing_ratio, lr=self.learning_rate, **hyper)
-            loss_st = out["loss_and_status"]   # [total_loss, step status]: read together, one host sync per batch
+            loss_st = self._train_step(molecules, conditions, teacher_forcing_ratio, hyper)
             if batch_idx == 0 or batch_idx % 25 == 0:  # Q16: second forward, post-update weights, T more coins
                 d = self._loss_dict(molecules, conditions, beta, teacher_forcing_ratio)
                 vals = torch.cat([loss_st, torch.stack([d["recon_loss"], d["kl_loss"], d["collapse_penalty"],
@@ -147,11 +177,15 @@ class ARCVAETrainerWithLoss:
             if status != 0.0:
                 # a device-side gate expired or a persistent sweep gave up in THIS step: the device has already
                 # skipped both Adam updates (the weights are those of the previous batch); stop here, not at epoch end
-                self.engine.check_gates()
-                raise RuntimeError(f"training step {batch_idx}: stream order was lost on the device (no update applied)")
+                self.poisoned = True
+                if self.engine is not None:
+                    self.engine.check_gates()
+                raise RuntimeError(f"training step {batch_idx}: stream order was lost on the device (the encoder's update "
+                                   "was skipped; the decoder's may already be applied: do not checkpoint this state)")
             if not np.isfinite(loss_val) or loss_val > 2000.0 or loss_val < -10.0:  # Q15
-                print(f"\nWARNING: loss explosion detected at batch {batch_idx}: {loss_val:.2e} "
-                      "(update already applied; value excluded from the epoch mean)")
+                if self.rank == 0:
+                    print(f"\nWARNING: loss explosion detected at batch {batch_idx}: {loss_val:.2e} "
+                          "(update already applied; value excluded from the epoch mean)")
                 self._loss_dict(molecules, conditions, beta, teacher_forcing_ratio)  # reference re-evaluates here
                 continue
             total_loss += loss_val
@@ -168,10 +202,11 @@ class ARCVAETrainerWithLoss:
     def _get_latent_stats(self):
         """trainer.py:524-545: encoder pass on the first 64 training rows, printed summary."""
         molecules, conditions = next(iter(self.dataset.to_batches(64, shuffle=False)))
-        mu, logvar = self.encoder(molecules, conditions)
-        m, lv = mu.cpu().numpy(), logvar.cpu().numpy()
-        print(f"   Latent Stats: mu=[{m.min():.3f}, {m.max():.3f}] (mean={m.mean():.3f}, std={m.std():.3f}), "
-              f"logvar=[{lv.min():.3f}, {lv.max():.3f}] (mean={lv.mean():.3f}, std={lv.std():.3f})")
+        mu, logvar = self._encode(molecules, conditions)      # (N ranks: every rank encodes the same 64 rows)
+        if self.rank == 0:
+            m, lv = mu.cpu().numpy(), logvar.cpu().numpy()
+            print(f"   Latent Stats: mu=[{m.min():.3f}, {m.max():.3f}] (mean={m.mean():.3f}, std={m.std():.3f}), "
+                  f"logvar=[{lv.min():.3f}, {lv.max():.3f}] (mean={lv.mean():.3f}, std={lv.std():.3f})")
         return mu, logvar
 
     @staticmethod
@@ -188,6 +223,11 @@ class ARCVAETrainerWithLoss:
 
     # ---- checkpoints / history (trainer.py:577-736) -----------------------------------------------------
     def save_checkpoint(self, epoch: int, is_best: bool = False):
+        if self.poisoned:
+            raise RuntimeError("a training step lost its stream order (encoder and decoder may be one update apart): "
+                               "refusing to checkpoint this state; resume from the last checkpoint")
+        if self.rank != 0:       # N ranks hold identical weights and optimizer state: rank 0 writes
+            return
         ck = {"epoch": np.array(epoch), "history_json": np.array(json.dumps(self.history))}
         for tag, mod in (("encoder", self.encoder), ("decoder", self.decoder)):
             st = mod.store
@@ -222,12 +262,16 @@ class ARCVAETrainerWithLoss:
         return int(ck["epoch"]) if "epoch" in ck else 0
 
     def save_history(self, path: str):
+        if self.rank != 0:
+            return
         p = Path(path) / "training_history.json"
         with open(p, "w") as f:
             json.dump(self.history, f, indent=2)
         print(f"    Saved history: {p}")
 
     def plot_history(self, save_path: str = None):
+        if self.rank != 0:
+            return
         try:
             import matplotlib
             matplotlib.use("Agg")

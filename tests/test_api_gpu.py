@@ -327,6 +327,9 @@ def test_trainer_stops_at_the_batch_whose_stream_order_was_lost(tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(vae.encoder.store.flat, before_e) and torch.equal(vae.decoder.store.flat, before_d)
     assert float(ws.scalars[15]) == 1.0 and bool(torch.isnan(ws.scalars[0]))
+    with pytest.raises(RuntimeError):                            # such a state is never checkpointed (the decoder's
+        trainer.save_checkpoint(0)                               # update may be in while the encoder's was skipped)
+    trainer.poisoned = False
     ws.psync[500] = 0
     if eng.gates is not None:                                    # the same through the gates' error word
         eng.gates.mem[eng.gates.ERR * 32] = 1
@@ -335,6 +338,7 @@ def test_trainer_stops_at_the_batch_whose_stream_order_was_lost(tmp_path):
         torch.cuda.synchronize()
         assert torch.equal(vae.encoder.store.flat, before_e) and torch.equal(vae.decoder.store.flat, before_d)
         eng.gates.mem[eng.gates.ERR * 32] = 0
+        trainer.poisoned = False
     np.random.seed(1)
     trainer._train_epoch_batches(0.0, 0.9)                       # and training continues once the words are clear
     torch.cuda.synchronize()

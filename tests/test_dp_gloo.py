@@ -25,8 +25,9 @@ DT = torch.float64
 class OracleOps:
     """StepOps backed by the oracle (CPU).  stats layout = csrc/latent.hip."""
 
-    def __init__(self, cfg, params, x, cond, eps, coins, T, lr, global_rows):
+    def __init__(self, cfg, params, x, cond, eps, coins, T, lr, global_rows, hyper=None):
         self.cfg, self.T, self.lr, self.coins = cfg, T, lr, coins
+        self.hy = dict(HYPER if hyper is None else hyper)
         self.global_rows = global_rows              # known a priori (the engine takes it as an argument too)
         self.order = []                             # issue order of the collectives' producers (same on every rank)
         self.p = {k: torch.tensor(v, dtype=DT, requires_grad=True) for k, v in params.items()}
@@ -56,7 +57,7 @@ class OracleOps:
         mc, lc = O.mlx_clip(mu, -3.0, 3.0), O.mlx_clip(logvar, -6.0, 3.0)
         var = torch.exp(lc)
         k = -0.5 * (1.0 + lc - mc * mc - var)
-        kf = O.mlx_maximum(O.mlx_maximum(k, 0.0), HYPER["free_bits"] / cfg.Z)
+        kf = O.mlx_maximum(O.mlx_maximum(k, 0.0), self.hy["free_bits"] / cfg.Z)
         rows = torch.tensor([float(mu.shape[0])], dtype=DT)
         return torch.cat([mc.sum(0), var.sum(0), k.sum().reshape(1), kf.sum().reshape(1), rows, ce.reshape(1)])
 
@@ -90,10 +91,10 @@ class OracleOps:
         mm, mv = lat[:Z] / Bg, lat[Z:2 * Z] / Bg
         agg = -0.5 * (1.0 + torch.log(mv) - mm * mm - mv).sum()
         mi = O.mlx_maximum(lat[2 * Z] / Bg - agg, 0.0)
-        d = HYPER["target_mi"] - mi
+        d = self.hy.get("target_mi", 4.85) - mi
         dpos = torch.where(torch.zeros_like(d) > d, torch.zeros_like(d), d)
         kl = lat[2 * Z + 1] / Bg
-        self._latent_part = HYPER["beta"] * kl + HYPER["lambda_collapse"] * dpos + HYPER["lambda_mi"] * dpos
+        self._latent_part = self.hy["beta"] * kl + self.hy["lambda_collapse"] * dpos + self.hy["lambda_mi"] * dpos
         self._Bg, self._mi, self._kl = float(Bg), float(mi), float(kl)
         self.order.append("backward_local")
         assert float(Bg) == float(self.global_rows)
