@@ -70,6 +70,52 @@ def executed_flops_per_step(V, E, H, Z, C, L, T, B):
     return float(enc_f + heads_f + dec_f + enc_b + heads_b + dec_b)
 
 
+def sampler_flops(V, E, H, C, L, rows):
+    """Contractions the greedy sampler executes for one batch of `rows` molecules, whatever max_length: the decoder is
+    stateless (Q1/Q2), so ONE dense pass over the rows x V (row, token) pairs decides every step of every row."""
+    G, R = 4 * H, rows * V
+    return float(2 * V * G * E + (L - 1) * 2 * R * G * H + 2 * R * V * H)
+
+
+def sampler_leg(torch, dev, reps):
+    """BASELINE.json configs[4]: models/decoder_sampling.py generate_with_temperature, 10 000 molecules as 10 batches of bs
+    1024 (the last one 784 rows), greedy, early stopping on (the API default), captured decode pass; max_length 80 (the API
+    default) and 128 (BASELINE's sequence bound).  Random-init weights of the default architecture."""
+    from models.vae import ARCVAE
+    vae = ARCVAE(vocab_size=V, embedding_dim=EMB, hidden_dim=256, latent_dim=128, num_conditions=C, num_layers=2, device=dev)
+    rs = np.random.RandomState(0)
+    conds = [torch.tensor(rs.standard_normal((b, C)).astype(np.float32), device=dev) for b in [1024] * 9 + [784]]
+    zs = [torch.zeros(c.shape[0], 128, device=dev) for c in conds]      # z is accepted and unused (Q2)
+    flops = sum(sampler_flops(V, EMB, 256, C, 2, c.shape[0]) for c in conds)
+    legs = {}
+    for max_len in (80, 128):
+        for c, z in ((conds[0], zs[0]), (conds[-1], zs[-1])):            # warm-up: capture both batch shapes
+            vae.decoder_sampling.generate_with_temperature(z, c, max_length=max_len)
+        times, ntok = [], 0
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ntok = 0
+            for c, z in zip(conds, zs):
+                ntok += vae.decoder_sampling.generate_with_temperature(z, c, max_length=max_len).numel()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
+        legs[f"max_length_{max_len}"] = {
+            "molecules_per_s": 10000 / dt, "tokens_per_s": ntok / dt, "ms_per_10k": 1e3 * dt, "reps": reps,
+            "tflops_executed": flops / dt / 1e12, "executed_frac_of_f32_mfma_peak": flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    return {"workload": "greedy sampling (models/decoder_sampling.py), 10k molecules = 9 x bs 1024 + 784, default AR-CVAE, "
+                        "early stopping on, captured decode pass, host wall time incl. the per-batch early-stop read "
+                        "(BASELINE.json configs[4])",
+            "dtype": "f32", "unit": "molecules/s", **legs,
+            "roofline": {"bound": "mfma", "limiter": "mfma", "kernel": "gemm_cell_zero_kernel + gemm_tile_kernel (dense decoder "
+                         "pass over B*V rows) + dec_sample_chain_kernel (LDS table walk)", "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "achieved": legs["max_length_80"]["tflops_executed"],
+                         "frac": legs["max_length_80"]["executed_frac_of_f32_mfma_peak"], "traffic": None,
+                         "note": "whole-leg figure (host wall clock over 10 captured passes): executed contraction FLOPs / time; "
+                                 "per-kernel times: profiles/r03_sampler_kernel_stats.csv"}}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +146,12 @@ def parse_args(argv=None):
     ap.add_argument("--configs2-steps", type=int, default=8,
                     help="timed steps of the BASELINE.json configs[2] legs (H512 Z256 L4, bs 512: the MFMA-bound regime) in fp32 "
                          "and in bf16 throughput mode, reported under `other_configs` (N = 1, default config; 0 = skip)")
+    ap.add_argument("--shard-steps", type=int, default=40,
+                    help="timed steps of the strong leg's shard probe at N = 1: the step at global_batch / 8 rows (the per-GPU "
+                         "shard of BASELINE.json configs[3]) on this one GPU (0 = skip)")
+    ap.add_argument("--sampler-reps", type=int, default=3,
+                    help="repetitions of the BASELINE.json configs[4] leg (10k molecules greedy sampling, bs 1024, max_length 80 "
+                         "and 128; N = 1, default config; 0 = skip)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the torch.distributed.run command --gpus N would start, and exit (no GPU touched)")
     return ap.parse_args(argv)
@@ -329,6 +381,17 @@ def main(argv=None):
             dt = float(tt.item())
         return dt, host_enq
 
+    def dp_form(dp_) -> str:
+        """Which data-parallel form the step ran in (arcvae_hip/dp.py), for the record next to the number."""
+        if dp_ is None:
+            return "single process (no collectives)"
+        ops = dp_.ops
+        if not getattr(ops, "gated", False):
+            return "event form: decoder bucket on a comm stream beside the sweep, encoder bucket after it"
+        return ("gated form: decoder bucket reduced early on side through a second communicator, encoder bucket on main after the join"
+                if getattr(ops, "early", True) else
+                "gated form, ARCVAE_DP_EARLY_REDUCE=0: the whole gradient bucket reduced on main after the join")
+
     def healthy(eng_) -> str:
         """'' when every device-side gate opened in order and no persistent sweep gave up, on EVERY rank."""
         bad, why = 0, ""
@@ -408,7 +471,7 @@ def main(argv=None):
             "config": {"workload": f"{wl_name}, bs {B}/GPU, T 128, tf 0.9, "
                                    f"beta 0 (epoch-0 schedule), fwd+bwd+Adam ({wl_ref})",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "launch_mode": mode, "fallback": fallback},
+                       "launch_mode": mode, "fallback": fallback, "dp_form": dp_form(dp), "gates_ok_all_ranks": True},
             "elbo": {"total": float(scal[0]), "recon": float(scal[1]), "kl": float(scal[2]),
                      "mutual_info": float(scal[7])},
             # algorithmic = the REFERENCE's FLOPs for this step (decoder over B*T positions, embedding
@@ -456,14 +519,65 @@ def main(argv=None):
                 strong = {"global_batch": G2, "rows_per_gpu": rows, "skipped": why}
             else:
                 sc2 = ws2.scalars.cpu().numpy()
+                f_ex2 = executed_flops_per_step(V, EMB, H, Z, C, L, T, rows)
                 strong = {"global_batch": G2, "rows_per_gpu": rows, "n_gpus": world, "steps": args.strong_steps,
                           "warmup": args.strong_warmup, "ms_per_step": 1e3 * dt2 / args.strong_steps,
                           "value": G2 * args.strong_steps / dt2, "unit": "sequences/s", "scaling": "strong",
                           "elbo": {"total": float(sc2[0]), "recon": float(sc2[1]), "kl": float(sc2[2])},
+                          "step_tflops_executed_per_gpu": f_ex2 / (dt2 / args.strong_steps) / 1e12,
+                          "step_executed_frac_of_f32_mfma_peak": f_ex2 / (dt2 / args.strong_steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                          "dp_form": dp_form(dp2), "gates_ok_all_ranks": True,
                           "bptt_kernel": ("lstm_bwd_persist_rs_kernel" if E.bptt_reduce_scatter_ok(ws2, dims)
                                           else "per-step launches (lstm_bwd_step*/tile kernels)")}
+                if rank == 0 and not args.no_roofline:
+                    strong["roofline"] = roofline_probe(eng2, ws2, torch)       # this leg's own dominant kernel, live
                 log(f"strong leg: global batch {G2} = {rows} rows/GPU x {world}: {strong['ms_per_step']:.3f} ms/step, "
                     f"{strong['value']:.0f} seq/s")
+            del step2, eng2, ws2, dp2
+            # ---- N = 1: the per-GPU shard of the 8-GPU run (global batch / 8 rows) timed on this one GPU, and what the two
+            # single-GPU figures imply for 8 GPUs BEFORE communication -- an estimate, labelled as such, until the driver's
+            # 8-GPU run measures the real thing
+            if (world == 1 and strong is not None and "value" in strong and args.shard_steps > 0 and G2 % 8 == 0
+                    and not args.force_dp):
+                torch.cuda.empty_cache()
+                srows = G2 // 8
+                eng5, ws5, dp5 = make_engine(srows, srows)
+                w5 = 8
+                step5 = stepper(eng5, ws5, dp5, make_inputs(srows, w5 + args.shard_steps, 267))
+                for i in range(w5):
+                    step5(i)
+                torch.cuda.synchronize()
+                why5 = healthy(eng5)
+                if not why5:
+                    dt5, _ = timed(step5, w5, args.shard_steps)
+                    why5 = healthy(eng5)
+                if why5:
+                    strong["shard_probe"] = {"rows": srows, "skipped": why5}
+                else:
+                    t_sh, t_full = dt5 / args.shard_steps, dt2 / args.strong_steps
+                    f_ex5 = executed_flops_per_step(V, EMB, H, Z, C, L, T, srows)
+                    strong["shard_probe"] = {
+                        "rows": srows, "ms_per_step": 1e3 * t_sh, "value": srows / t_sh, "unit": "sequences/s",
+                        "steps": args.shard_steps, "warmup": w5,
+                        "step_tflops_executed": f_ex5 / t_sh / 1e12,
+                        "step_executed_frac_of_f32_mfma_peak": f_ex5 / t_sh / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "fwd_kernel": ("lstm_fwd_persist_kernel, two-group form (two blocks per CU)"
+                                       if _lib.load().arcvae_enc_lstm_persist_groups(srows, H, L) == 2 else
+                                       ("lstm_fwd_persist_kernel" if E.persistent_forward_ok(ws5, dims) else "per-step launches")),
+                        "bptt_kernel": ("lstm_bwd_persist_rs_kernel" if E.bptt_reduce_scatter_ok(ws5, dims)
+                                        else "per-step launches (lstm_bwd_step*/tile kernels)"),
+                        "what": f"the {srows}-row shard one GPU of the 8-GPU strong-scaling run steps (no collectives here)"}
+                    if not args.no_roofline:
+                        strong["shard_probe"]["roofline"] = roofline_probe(eng5, ws5, torch)
+                    strong["estimate_8gpu"] = {
+                        "speedup_before_communication": 8.0 * (srows / t_sh) / (G2 / t_full),
+                        "how": f"8 x ({srows} rows / {1e3 * t_sh:.3f} ms) / ({G2} rows / {1e3 * t_full:.3f} ms), both measured in "
+                               "this process on ONE GPU; an ESTIMATE: the stats all-reduce on the chain and the exposed encoder "
+                               "bucket are not in it (unmeasured on more than one GPU)",
+                        "north_star_target": 6.5}
+                    log(f"shard probe: {srows} rows: {1e3 * t_sh:.3f} ms/step = {srows / t_sh:.0f} seq/s -> 8-GPU estimate "
+                        f"{strong['estimate_8gpu']['speedup_before_communication']:.2f}x before communication")
+                del step5, eng5, ws5
         if rank == 0:
             out["strong"] = strong
     # ---- bf16 throughput-mode leg (SURVEY.md 8(d) Config 2 "bf16-in/fp32-acc"): the same workload on
@@ -545,12 +659,17 @@ def main(argv=None):
                 legs[prec] = {"skipped": why}
             else:
                 sq = B2 * args.configs2_steps / dt4
+                f_ex4 = executed_flops_per_step(V, EMB, H2, Z2, C, L2, T, B2)
                 legs[prec] = {"dtype": "f32" if prec == "fp32" else "bf16", "ms_per_step": 1e3 * dt4 / args.configs2_steps,
                               "value": sq, "unit": "sequences/s", "steps": args.configs2_steps, "warmup": w2,
                               "step_tflops_algorithmic": sq * f_seq2 / 1e12,
+                              "step_tflops_executed": f_ex4 / (dt4 / args.configs2_steps) / 1e12,
                               "elbo_total": float(ws4.scalars.cpu().numpy()[0])}
                 if prec == "fp32":
                     legs[prec]["frac_of_f32_mfma_peak"] = sq * f_seq2 / 1e12 / PEAK_F32_MFMA_TFLOPS
+                    legs[prec]["executed_frac_of_f32_mfma_peak"] = legs[prec]["step_tflops_executed"] / PEAK_F32_MFMA_TFLOPS
+                    if not args.no_roofline:
+                        legs[prec]["roofline"] = roofline_probe(eng4, ws4, torch)   # the MFMA-bound regime's dominant kernel, live
                 else:
                     legs[prec]["frac_of_bf16_mfma_peak"] = sq * f_seq2 / 1e12 / 2500.0
                     legs[prec]["note"] = "throughput mode: not a parity path (tests/test_bf16_mode_gpu.py states its tolerance)"
@@ -559,6 +678,15 @@ def main(argv=None):
             torch.cuda.empty_cache()
         out["other_configs"] = {"configs[2]": {"workload": "big AR-CVAE V80 E128 H512 Z256 C1 L4, bs 512/GPU, T 128, tf 0.9, "
                                                            "fwd+bwd+Adam (BASELINE.json configs[2])", **legs}}
+    # ---- BASELINE.json configs[4]: autoregressive sampling, 10k molecules, bs 1024 (N = 1 only; replicas need no collective)
+    if (world == 1 and args.precision == "fp32" and args.sampler_reps > 0 and args.config == "default"
+            and not args.batch_per_gpu and not args.force_dp):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        out.setdefault("other_configs", {})["configs[4]"] = sampler_leg(torch, dev, args.sampler_reps)
+        sl = out["other_configs"]["configs[4]"]
+        log(f"configs[4] sampler: {sl['max_length_80']['ms_per_10k']:.2f} ms / 10k molecules at max_length 80 "
+            f"({sl['max_length_80']['molecules_per_s']:.0f} molecules/s), {sl['max_length_128']['ms_per_10k']:.2f} ms at 128")
     if rank == 0:
         if args.cpu_steps > 0 and args.config == "default" and world == 1:   # the CPU baseline is an N = 1 figure
             log(f"cpu baseline on {host_cores()} host cores")
@@ -580,13 +708,15 @@ def _lib_load():
 def roofline_probe(eng, ws, torch):
     """Live HIP-event timing of the dominant kernel on the stream it is launched on.
 
-    Dominant kernel (largest share of device time, profiles/): lstm_bwd_step_kernel, one launch of the BPTT
-    wavefront.  A steady-state launch carries 2L-1 single-source jobs (L cell steps dG_{t+1} . Wh^T and L-1
-    input-gradient projections dG^{l+1}_t . Wx^T), each a [B,4H] x [4H,H] contraction = 2*B*4H*H FLOP.
-    Timed as the whole arcvae_enc_lstm_backward call (T+2(L-1) dependent launches, replayed as one linear
-    hipGraph) between two events on the launching stream, divided by the launch count: launches of a
-    dependent chain are back to back, so this is the per-launch figure rocprofv3's kernel trace reports
-    (its start stamp of launch n+1 is the end stamp of launch n).
+    Dominant kernel of a training step at this shape = the BPTT sweep of the encoder stack, in whichever family the
+    engine runs it (profiles/): lstm_bwd_persist_rs_kernel (persistent reduce-scatter sweep: up to 128 rows per GPU at
+    H 256, one launch per chunk, a "launch" below = one TICK of it), lstm_bwd_tile_kernel / lstm_bwd_tile_ks_kernel (the
+    register-tiled step kernels of the MFMA-bound regime: bs 2048, configs[2]) or lstm_bwd_step / step2_kernel (per-step
+    launches).  A tick / launch carries 2L-1 single-source jobs (L cell steps dG_{t+1} . Wh^T and L-1 input-gradient
+    projections dG^{l+1}_t . Wx^T), each a [B,4H] x [4H,H] contraction = 2*B*4H*H FLOP.
+    Timed as the whole sweep through the engine's own call (replayed as one linear hipGraph) between two events on
+    the launching stream, divided by the tick / launch count: launches of a dependent chain are back to back, so this
+    is the per-launch figure rocprofv3's kernel trace reports (its start stamp of launch n+1 is the end stamp of n).
     `traffic`: fabric-side bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md
     HBM section), taken from profiles/ (separate --pmc passes), not measured here.
     """

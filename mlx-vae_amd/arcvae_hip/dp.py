@@ -140,6 +140,12 @@ class EngineOps:
             flag = torch.tensor([1.0 if self.gated else 0.0], device=engine.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             self.gated = bool(flag.item() > 0.5)
+        # ARCVAE_DP_EARLY_REDUCE=0: round 1's ordering -- nothing is reduced beside the sweeps: the whole bucket [enc.grad |
+        # dec.grad | CE sum] is ONE all-reduce on main after the join, and the decoder's Adam update moves into the finish
+        # segment.  The default (early decoder reduce on side, second communicator) is UNMEASURED on more than one GPU: an RCCL
+        # kernel that waits for a slower peer holds CU resources beside persistent sweeps that need a resident block on
+        # every CU; this switch is the fallback if that turns out to cost more than the overlap gains.
+        self.early = os.environ.get("ARCVAE_DP_EARLY_REDUCE", "1") != "0"
         if self.gated:
             self._make_bucket()
             self.recon_stat = None
@@ -216,8 +222,10 @@ class EngineOps:
             ws.stats[2 * Z + 3:2 * Z + 4].copy_(self.bucket_recon)   # GLOBAL CE sum (side reduced it long ago)
             ga, gb = eng.guards(ws)
             call("arcvae_loss_finalize", ptr(ws.stats), ptr(ws.scalars), Z, ws.T, ga, gb, stream_ptr())
+            if not self.early:                                        # (early form: the decoder's update rode on side)
+                adam_update(eng.dec, self.lr, guards=(ga, gb))
             adam_update(eng.enc, self.lr, guards=(ga, gb))
-        self.run("dp_finish", fn, torch.cuda.current_stream())
+        self.run("dp_finish" if self.early else "dp_finish_late", fn, torch.cuda.current_stream())
 
     # ---- StepOps ----------------------------------------------------------------------------------------
     def forward_local(self) -> None:
@@ -255,18 +263,18 @@ class EngineOps:
 
     def early_buckets(self) -> List[torch.Tensor]:
         if self.gated:
-            return [self.bucket_dec]
+            return [self.bucket_dec] if self.early else []
         torch.cuda.current_stream().wait_event(self.eng.ev_dec_bwd)
         return [self.eng.dec.grad]
 
     def early_done(self) -> None:
-        if self.gated:
+        if self.gated and self.early:
             self._dec_adam_gated()                   # decoder gradients are GLOBAL: its Adam update rides on side too
 
     def late_buckets(self) -> List[torch.Tensor]:
         if self.gated:
             self._join_gated()
-            return [self.bucket_enc]
+            return [self.bucket_enc] if self.early else [self.bucket]   # (late form: side wrote its half before the join)
         return [self.eng.enc.grad]
 
     def apply_update(self) -> None:
@@ -352,6 +360,10 @@ class EngineDataParallel:
             self._early_group = drv.early_group
             self._drivers[key] = drv
         drv.step()
+        # A rank whose sweep gave up (or whose gate expired) skipped its update and fed garbage into the buckets: every rank
+        # must see that at THIS batch -- the step status travels as one more (tiny) all-reduce, so that all ranks raise
+        # together instead of one leaving the others parked in the next collective.
+        dist.all_reduce(ws.scalars[15:16], op=dist.ReduceOp.MAX, group=self.group)
         return ws
 
     def forward_loss(self, x, cond, eps, coins, **hyper):

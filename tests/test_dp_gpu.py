@@ -107,6 +107,18 @@ def _compare_with_single_process(cfg_name, B, T, ret):
     assert rel_err(ret["dec"], dec.flat.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.timeout(600)
+def test_two_ranks_late_reduce_form(monkeypatch):
+    """ARCVAE_DP_EARLY_REDUCE=0 (the fallback ordering: nothing reduced beside the sweeps, ONE all-reduce of the whole
+    gradient bucket on main after the join, the decoder's Adam in the finish segment) gives the same step."""
+    monkeypatch.setenv("ARCVAE_DP_EARLY_REDUCE", "0")
+    world, B, T = 2, 8, 12
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), "tiny", B, T, ret), nprocs=world, join=True)
+    _compare_with_single_process("tiny", B, T, ret)
+
+
 @pytest.mark.timeout(900)
 def test_two_ranks_persistent_sweeps_under_the_collectives():
     """H = 256, L = 2 (the default model's recurrence): persistent forward sweep, persistent reduce-scatter BPTT, gates
