@@ -767,7 +767,8 @@ def roofline_probe(eng, ws, torch):
     tiled = (not persistent) and bool(_lib_load().arcvae_enc_lstm_tiled(B, d.H, d.L) & 2)
     bf16 = getattr(eng, "precision", "fp32") == "bf16" and (persistent or tiled)   # the sweep really runs bf16 blocks / tiles
     kernel = ("lstm_bwd_persist_rs_kernel" if persistent else
-              ("lstm_bwd_tile_kernel / lstm_bwd_tile_ks_kernel" if tiled else "lstm_bwd_step_kernel"))
+              ("lstm_bwd_tile_kernel / lstm_bwd_tile_ks_kernel" if tiled else
+               ("lstm_bwd_step2_kernel" if B >= 256 else "lstm_bwd_step_kernel")))
     peak = 2500.0 if bf16 else PEAK_F32_MFMA_TFLOPS       # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
     # traffic: fabric-side bytes per tick / launch from the newest committed rocprofv3 --pmc summary (separate passes,
     # tools/pmc.sh; 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction) -- a profile figure, named by its file, not
@@ -805,6 +806,11 @@ def roofline_probe(eng, ws, torch):
                 "`bound` names the section-8(d) denominator (f32-input MFMA peak, exact-f32 path); the LIMITER is the "
                 "tick latency of a 259-tick dependent chain (exchange through the XCD's L2, block barriers, epilogue), "
                 "not MFMA issue or HBM bytes: see tick_model")
+    elif tiled:
+        note = ("achieved = isolated BPTT sweep (HIP events on its stream) / launches; the register-tiled step kernels of the "
+                "MFMA-bound regime: every wave owns a (16 MT rows) x (16 NT columns) tile over the whole contraction, operands "
+                "straight from k-chunk-major copies.  `bound` = f32-input MFMA peak; what is left to the peak is the launch seam "
+                "(1.6 us per dependent launch) and the cell epilogue's HBM traffic behind every contraction (DESIGN.md section 5)")
     else:
         note = ("achieved = isolated BPTT sweep (HIP events on its stream); in_step_* = start-to-start cadence of the "
                 "same launches inside the last timed step (device-side stamps, side-stream GEMMs running beside "
@@ -812,7 +818,8 @@ def roofline_probe(eng, ws, torch):
                 "dependent-chain seam (1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6")
     if bf16:
         note += "  (throughput mode: bf16 operands, so `peak` is the dense bf16 MFMA peak; not the parity path)"
-    return {"bound": "mfma", "limiter": "latency", "kernel": kernel, "achieved": ach, "peak": peak,
+    return {"bound": "mfma", "limiter": "mfma + launch seam" if tiled else "latency", "kernel": kernel, "achieved": ach,
+            "peak": peak,
             "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
             "us_per_launch": us, "launches_per_sweep": launches,
             "flop_per_launch": flops_total / launches, "tick_model": tick_model, "note": note}
