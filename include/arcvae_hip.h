@@ -12,13 +12,14 @@
  *     contiguous row-major float32 unless stated, parameter tensors 16-byte aligned;
  *   - asynchronous on `stream` (a hipStream_t passed as void*); safe under hipGraph capture
  *     (no sync, no malloc); re-entrant: no global mutable host state -- chunk indices, trace buffers and
- *     sync scratch are arguments; the only process-wide values are ARCVAE_* tuning knobs read once
- *     from the environment (immutable afterwards);
+ *     sync scratch are arguments; the only process-wide values are the ARCVAE_* tuning knobs of the environment (most
+ *     are read once per process; the kernel-family selectors -- ARCVAE_STEP_TILE, ARCVAE_RING, ARCVAE_PERSIST*,
+ *     ARCVAE_RS_* -- are read at every call, so a caller that changes them must drop its captured graphs);
  *   - `const float* const*` arguments are HOST arrays of device pointers (one per LSTM layer);
  *   - gradients are accumulated ("+="): zero the flat gradient buffer once per step;
  *   - float32 arithmetic throughout (the reference's dtype), contractions on the exact-f32
  *     MFMA forms; hidden_dim a multiple of 64 and <= 512, num_layers <= 8, 1 <= num_conditions <= 8,
- *     vocab_size <= 127 (anything else is ARCVAE_ERR_ARG, never a silent fallback).
+ *     vocab_size <= 255 (anything else is ARCVAE_ERR_ARG, never a silent fallback).
  */
 #ifndef ARCVAE_HIP_H
 #define ARCVAE_HIP_H
@@ -299,11 +300,15 @@ int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int rows, int n
                              arcvae_stream_t stream);
 int arcvae_transpose_batched(const float* const* src, float* const* dst, const int* rows, const int* cols,
                              int n, arcvae_stream_t stream);
+/* Diagnostic / test entry point: `blocks` workgroups of `threads` threads (a multiple of 64) that hold `lds_bytes` of LDS each
+ * and wait `spin_us` microseconds -- a stand-in for a communication kernel that occupies CU resources on another stream
+ * beside the persistent sweeps (tests/test_occupancy_gpu.py).  Computes nothing. */
+int arcvae_debug_occupy(int blocks, int threads, int lds_bytes, int spin_us, arcvae_stream_t stream);
 int arcvae_scale_inplace(float* x, long n, float s, arcvae_stream_t stream);
 int arcvae_zero(float* x, int rows, int cols, int ld, arcvae_stream_t stream);
 /* Token-table gradient dT [V,4H] of an LSTM layer-0 input projection folded back in one launch (backward of
  * nn.Embedding + the x.Wx^T term of nn.LSTM, models/encoder.py:93,98 and models/decoder.py:154-166):
- * dEmb [V,E] += dT . Wx0[:, :E];  dWx0[:, :E] += dT^T . emb (row stride ldw);  db0 [4H] += colsum(dT).  V <= 128. */
+ * dEmb [V,E] += dT . Wx0[:, :E];  dWx0[:, :E] += dT^T . emb (row stride ldw);  db0 [4H] += colsum(dT). */
 int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw, const float* emb, float* dEmb, float* dWx0,
                           float* db0, int V, int E, int G, arcvae_stream_t stream);
 /* Device-side gates (no reference counterpart): cross-stream ordering by a one-wave polling kernel instead of an

@@ -79,6 +79,7 @@ SIGNATURES = {
     "arcvae_segsum_rows_accum": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "arcvae_transpose_batched": [_pp, _pp, _ip, _ip, _i, _vp],
     "arcvae_scale_inplace": [_vp, _l, _f, _vp],
+    "arcvae_debug_occupy": [_i, _i, _i, _i, _vp],
     "arcvae_zero": [_vp, _i, _i, _i, _vp],
     "arcvae_table_finalize": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "arcvae_gate_wait": [_vp, _vp, C.c_uint, C.c_uint, _i, C.c_uint, _vp, _vp],

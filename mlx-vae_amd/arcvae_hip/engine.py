@@ -53,8 +53,10 @@ class ModelDims:
             raise ValueError("num_layers must be in [1, 8]")
         if not (1 <= self.C <= 8):
             raise ValueError("num_conditions must be in [1, 8]")
-        if not (2 <= self.V <= 127):
-            raise ValueError("vocab_size must be in [2, 127]")
+        if not (2 <= self.V <= 255):
+            # the decoder is evaluated over all B*V (row, token) pairs and its cross-entropy backward keeps a V x V count
+            # histogram per batch row in LDS (16-bit counts from V = 128 on: 131 KB at 255) -- INTEGRATION.md section 5
+            raise ValueError("vocab_size must be in [2, 255] (the vocabulary-dense decoder's per-row V x V histogram lives in LDS)")
 
 
 class Workspace:
@@ -169,7 +171,7 @@ def fused_wgrad_ok(ws, d: ModelDims) -> bool:
     lstm_bwd_persist_rs_kernel: no weight-gradient GEMMs, no chunks).  Parity-green, but measured SLOWER than the sweep +
     GEMMs on aux / side (the tick grows from 2.8 to 4.7 us -- nothing added to the chain's wave
     hides -- which costs 240 us per step against the 220 us the separate GEMMs cost), so it is not the default."""
-    return os.environ.get("ARCVAE_FUSED_WGRAD", "0") == "1" and bptt_reduce_scatter_ok(ws, d)
+    return os.environ.get("ARCVAE_FUSED_WGRAD", "0") == "1" and d.V <= 128 and bptt_reduce_scatter_ok(ws, d)
 
 
 def persistent_forward_ok(ws: Workspace, d: ModelDims) -> bool:

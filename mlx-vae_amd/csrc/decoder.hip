@@ -277,21 +277,27 @@ __global__ __launch_bounds__(64) void dec_chain_kernel(const int32_t* __restrict
 // ---- d(recon)/d(dense logits) ---------------------------------------------------------------
 // recon = inv_count * sum_{b,t} CE(logits[b,fed[b,t]], x[b,t])  (inv_count = 1/(B_global*T), Q3)
 // dlogits[b,v,w] = inv_count * (cnt[b,v] * softmax(logits[b,v])[w] - hist[b,v,w])
+// PACK (vocabularies of 128..255 tokens): the V x V histogram as 16-bit counts, two per LDS word (a count is at most T <
+// 65536, so a packed add never carries into its neighbour): 131 KB at V = 255 instead of 260 KB.
+template <bool PACK>
 __global__ __launch_bounds__(256) void dec_ce_bwd_kernel(const int32_t* __restrict__ x,
                                                          const int32_t* __restrict__ fed,
                                                          const float* __restrict__ logits,
                                                          const float* __restrict__ lse, float* dlogits, int T,
                                                          int V, float inv_count) {
     extern __shared__ int32_t sm[];
-    int32_t* hist = sm;          // [V*V]
-    int32_t* cnt = sm + V * V;   // [V]
+    const int nh = PACK ? (V * V + 1) / 2 : V * V;
+    int32_t* hist = sm;          // [V*V] counts (PACK: 16 bits each)
+    int32_t* cnt = sm + nh;      // [V]
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < V * V + V; i += 256) sm[i] = 0;
+    for (int i = tid; i < nh + V; i += 256) sm[i] = 0;
     __syncthreads();
     for (int t = tid; t < T; t += 256) {
         const int f = min(max(fed[(long)b * T + t], 0), V - 1);
         const int tg = min(max(x[(long)b * T + t], 0), V - 1);
-        atomicAdd(&hist[f * V + tg], 1);
+        const int i = f * V + tg;
+        if (PACK) atomicAdd(&hist[i >> 1], 1 << (16 * (i & 1)));
+        else atomicAdd(&hist[i], 1);
         atomicAdd(&cnt[f], 1);
     }
     __syncthreads();
@@ -300,7 +306,10 @@ __global__ __launch_bounds__(256) void dec_ce_bwd_kernel(const int32_t* __restri
         const long r = (long)b * V + v;
         const int cv = cnt[v];
         float d = 0.f;
-        if (cv) d = ((float)cv * expf(logits[r * V + (i - v * V)] - lse[r]) - (float)hist[i]) * inv_count;
+        if (cv) {
+            const int h = PACK ? (int)(((unsigned)hist[i >> 1] >> (16 * (i & 1))) & 0xffffu) : hist[i];
+            d = ((float)cv * expf(logits[r * V + (i - v * V)] - lse[r]) - (float)h) * inv_count;
+        }
         dlogits[r * V + (i - v * V)] = d;
     }
 }
@@ -400,9 +409,16 @@ extern "C" int arcvae_dec_chain_ce(const int32_t* x, const uint8_t* coins, const
 extern "C" int arcvae_dec_ce_backward(const int32_t* x, const int32_t* fed, const float* logits, const float* lse,
                                       float* dlogits, int B, int T, int V, float inv_count, hipStream_t stream) {
     if (!x || !fed || !logits || !lse || !dlogits || B <= 0 || T <= 0 || V <= 0) return ARCVAE_ERR_ARG;
+    if (V > 255 || T > 65535) return ARCVAE_ERR_ARG;   // vocab_size <= 255 (the V x V LDS histogram; 16-bit counts from 128 on)
     const size_t lds = (size_t)(V * V + V) * sizeof(int32_t);
-    if (lds > 64 * 1024) return ARCVAE_ERR_ARG;  // V <= 127
-    hipLaunchKernelGGL(dec_ce_bwd_kernel, dim3(B), dim3(256), lds, stream, x, fed, logits, lse, dlogits, T, V,
+    if (lds <= 64 * 1024) {                            // V <= 127: 32-bit counts
+        hipLaunchKernelGGL(dec_ce_bwd_kernel<false>, dim3(B), dim3(256), lds, stream, x, fed, logits, lse, dlogits, T, V,
+                           inv_count);
+        return arcvae_launch_status();
+    }
+    const size_t lds16 = (size_t)((V * V + 1) / 2 + V) * sizeof(int32_t);   // 131 KB at V = 255
+    (void)hipFuncSetAttribute((const void*)dec_ce_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(dec_ce_bwd_kernel<true>, dim3(B), dim3(256), lds16, stream, x, fed, logits, lse, dlogits, T, V,
                        inv_count);
     return arcvae_launch_status();
 }

@@ -225,24 +225,30 @@ __global__ __launch_bounds__(256) void table_finalize_kernel(const float* __rest
         const int et = bid % etiles64, g0 = (bid / etiles64) * 16;
         const int e64 = tid & 63, q = tid >> 6;
         const int e0 = et * 64, e = e0 + e64;
-        float* tt = sh;                               // dT^T tile [V][16]
-        float* em = sh + 128 * 16;                    // emb tile  [V][64]
-        for (int i = tid; i < V * 16; i += 256) tt[i] = dT[(long)(i >> 4) * G + g0 + (i & 15)];
-        for (int i = tid; i < V * 64; i += 256) {
-            const int v = i >> 6, ee = i & 63;
-            em[i] = (e0 + ee < E) ? emb[(long)v * E + e0 + ee] : 0.f;
-        }
-        __syncthreads();
-        if (e < E) {
-            float acc[4];
+        float* tt = sh;                               // dT^T tile [128][16]   (K = V in chunks of 128 tokens)
+        float* em = sh + 128 * 16;                    // emb tile  [128][64]
+        float acc[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = 0.f;
-#pragma unroll 4
-            for (int v = 0; v < V; ++v) {
-                const float x = em[v * 64 + e64];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fmaf(tt[v * 16 + q * 4 + i], x, acc[i]);
+        for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+        for (int vb = 0; vb < V; vb += 128) {
+            const int vn = min(128, V - vb);
+            if (vb) __syncthreads();
+            for (int i = tid; i < vn * 16; i += 256) tt[i] = dT[(long)(vb + (i >> 4)) * G + g0 + (i & 15)];
+            for (int i = tid; i < vn * 64; i += 256) {
+                const int v = i >> 6, ee = i & 63;
+                em[i] = (e0 + ee < E) ? emb[(long)(vb + v) * E + e0 + ee] : 0.f;
             }
+            __syncthreads();
+            if (e < E) {
+#pragma unroll 4
+                for (int v = 0; v < vn; ++v) {
+                    const float x = em[v * 64 + e64];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(tt[v * 16 + q * 4 + i], x, acc[i]);
+                }
+            }
+        }
+        if (e < E) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) atomicAdd(dWx0 + (long)(g0 + q * 4 + i) * ldw + e, acc[i]);   // atomic: two
             // chunks' tables may be folded at the same time on different streams (engine: side and main)
@@ -407,11 +413,11 @@ extern "C" int arcvae_segsum_rows_accum(const float* X, const int32_t* seg, int 
 }
 
 // dEmb [V,E] += dT . Wx0[:, :E];  dWx0[:, :E] += dT^T . emb  (row stride ldw >= E);  db0 [4H] += colsum(dT).
-// dT [V,4H] (V <= 128, 4H % 16 == 0).  One launch (see table_finalize_kernel).
+// dT [V,4H] (4H % 16 == 0).  One launch (see table_finalize_kernel).
 extern "C" int arcvae_table_finalize(const float* dT, const float* Wx0, int ldw, const float* emb, float* dEmb,
                                      float* dWx0, float* db0, int V, int E, int G, hipStream_t stream) {
     if (!dT || !Wx0 || !emb || !dEmb || !dWx0 || !db0) return ARCVAE_ERR_ARG;
-    if (V <= 0 || V > 128 || E <= 0 || G <= 0 || (G % 16) != 0 || ldw < E) return ARCVAE_ERR_ARG;
+    if (V <= 0 || E <= 0 || G <= 0 || (G % 16) != 0 || ldw < E) return ARCVAE_ERR_ARG;
     if ((G % TF_KS) != 0) return ARCVAE_ERR_ARG;
     const int etiles = ceil_div(E, 128);
     const int nA = ceil_div(V, TF_ROWS) * etiles * (G / TF_KS), nB = (G / 16) * ceil_div(E, 64), nC = ceil_div(G, 256);
@@ -533,6 +539,28 @@ extern "C" int arcvae_gate_wait(const unsigned* flag, unsigned* steps, unsigned 
 extern "C" int arcvae_gate_set(unsigned* flag, unsigned value, int add, hipStream_t stream) {
     if (!flag) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(gate_set_kernel, dim3(1), dim3(64), 0, stream, flag, value, add);
+    return arcvae_launch_status();
+}
+
+// Diagnostic / test entry point (tests/test_occupancy_gpu.py): a stand-in for a communication kernel -- `blocks` workgroups
+// of `threads` threads that hold `lds_bytes` of LDS each and do nothing but wait `spin_us` microseconds (wall clock), on
+// `stream`.  Used to show that the persistent sweeps (which need a resident block on every CU) survive a neighbour that
+// occupies CU resources: RCCL's channel kernels on another stream behave like this while they wait for a peer.
+namespace {
+__global__ void occupy_kernel(unsigned long long ticks, int lds_floats) {
+    extern __shared__ float occ_lds[];
+    for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) occ_lds[i] = 0.f;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+extern "C" int arcvae_debug_occupy(int blocks, int threads, int lds_bytes, int spin_us, hipStream_t stream) {
+    if (blocks <= 0 || blocks > 4096 || threads <= 0 || threads > 1024 || (threads % 64) != 0 || lds_bytes < 0 ||
+        lds_bytes > 150 * 1024 || spin_us < 0 || spin_us > 100000)
+        return ARCVAE_ERR_ARG;
+    (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, stream,
+                       (unsigned long long)spin_us * 100ull, lds_bytes / 4);
     return arcvae_launch_status();
 }
 

@@ -41,6 +41,35 @@ def test_arcvae_call_matches_reference_forward():
         assert_elem(got_t.cpu().numpy(), ref[name].numpy(), name, ELEM_ATOL_FWD)
 
 
+def test_arcvae_with_constructor_defaults_matches_reference_forward():
+    """ARCVAE(vocab_size) alone -- every other argument at the reference's constructor default (models/vae.py:18-27:
+    E 256, H 512, Z 200, C 6, L 3): forward API surface against the oracle."""
+    from models.vae import ARCVAE
+    vae = ARCVAE(95)
+    assert (vae.encoder.embedding_dim, vae.encoder.hidden_dim, vae.latent_dim, vae.encoder.num_conditions,
+            vae.encoder.num_layers) == (256, 512, 200, 6, 3)
+    cfg = O.Config(vocab_size=95, embedding_dim=256, hidden_dim=512, latent_dim=200, num_conditions=6, num_layers=3)
+    params = O.init_params(cfg, 1234)
+    vae.encoder.load_state_dict(params, prefix="encoder.")
+    vae.decoder.load_state_dict(params, prefix="decoder.")
+    B, T = 7, 18
+    x, cond = O.synthetic_batch(cfg, B, T, 67)
+    eps = np.random.RandomState(4321).standard_normal((B, cfg.Z)).astype(np.float32)
+    coins = O.draw_coins(np.random.RandomState(5), T, 0.5)
+    logits, mu, logvar, z = vae(torch.tensor(x), torch.tensor(cond), target_seq=torch.tensor(x), teacher_forcing_ratio=0.5,
+                                eps=torch.tensor(eps), coins=coins)
+    torch.cuda.synchronize()
+    p64 = O.to_torch(params, torch.float64)
+    pe = {k[len("encoder."):]: v for k, v in p64.items() if k.startswith("encoder.")}
+    pd = {k[len("decoder."):]: v for k, v in p64.items() if k.startswith("decoder.")}
+    with torch.no_grad():
+        mu_r, lv_r = O.encoder_forward(pe, torch.tensor(x, dtype=torch.int64), torch.tensor(cond, dtype=torch.float64), cfg.L)
+        z_r = O.reparameterize(mu_r, lv_r, torch.tensor(eps, dtype=torch.float64))
+        lg_r, _ = O.decoder_forward(pd, z_r, torch.tensor(cond, dtype=torch.float64), cfg.L, torch.tensor(x, dtype=torch.int64), coins)
+    assert rel_err(mu.cpu().numpy(), mu_r.numpy()) < 1e-4 and rel_err(logvar.cpu().numpy(), lv_r.numpy()) < 1e-4
+    assert rel_err(z.cpu().numpy(), z_r.numpy()) < 1e-4 and rel_err(logits.cpu().numpy(), lg_r.numpy()) < 1e-4
+
+
 def test_decoder_draws_coins_from_the_global_numpy_stream():
     cfg, B, T = TINY, 4, 12
     params, x, cond, eps, _ = make_case(cfg, B, T, 0.5)

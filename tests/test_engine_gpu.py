@@ -92,6 +92,21 @@ def test_step_default_shape():
     _check_step(DEFAULT, 64, 128, 0.9, True)
 
 
+def test_step_at_the_reference_constructor_defaults():
+    """The reference's CONSTRUCTOR defaults (models/vae.py:18-27: embedding 256, hidden 512, latent 200, 6 conditions,
+    3 layers -- not train.py's argparse defaults) with a 95-symbol alphabet: full step against the fp64 oracle."""
+    cfg = O.Config(vocab_size=95, embedding_dim=256, hidden_dim=512, latent_dim=200, num_conditions=6, num_layers=3)
+    _check_step(cfg, 12, 20, 0.7, True)
+
+
+@pytest.mark.parametrize("V,B,T", [(128, 6, 14), (200, 9, 24), (255, 5, 40)])
+def test_step_with_vocabularies_above_127(V, B, T):
+    """SELFIES alphabets of 128..255 symbols (round 3: the decoder's per-row V x V count histogram holds 16-bit counts
+    in LDS from 128 on; the token-table fold walks the vocabulary in chunks of 128): full step against the oracle."""
+    cfg = O.Config(vocab_size=V, embedding_dim=32, hidden_dim=64, latent_dim=16, num_conditions=2, num_layers=2)
+    _check_step(cfg, B, T, 0.6, False)
+
+
 def test_adam_trajectory_matches_oracle():
     """5 optimizer steps on one batch: parameters and loss follow the oracle (fp32 oracle, fp32 engine)."""
     cfg, B, T = TINY, 8, 12
