@@ -162,7 +162,8 @@ int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
  * BASELINE.json configs[3]), else 1.  Two groups: 512 blocks, two per CU; every XCD's 17..32 rows are two independent
  * recurrences of up to 16 rows with their own flag lines, and a CU's two blocks serve different groups, so that one group's
  * exchange latency sits under the other's matrix work.  Such a step uses sync_ws words [1024, 4352)
- * as well: re-arm 4352 words (arcvae_enc_prologue n_sync) instead of 848; part_ws as for RG = 4. */
+ * as well; a step re-arms 4864 words (arcvae_enc_prologue n_sync: the one-group words [0, 848), the two-group words and the
+ * reduce-scatter sweep's "gathered" words [4352, 4864) of its single-buffered exchange); part_ws as for RG = 4. */
 int arcvae_enc_lstm_persist_groups(int B, int H, int L);
 int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
                                            const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,

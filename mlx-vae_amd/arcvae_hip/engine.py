@@ -99,7 +99,8 @@ class Workspace:
         #                                          BPTT sweeps' at [512, 848), [500] = the sticky error word of both; the
         #                                          two-group forms' (129..256 rows per GPU) at [1024, 4352)
         # words a step's prologue re-arms (arcvae_enc_lstm_persist_groups: two groups of 16 rows per XCD, two blocks per CU)
-        self.psync_words = 4352 if _lib.load().arcvae_enc_lstm_persist_groups(B, H, L) == 2 else 848
+        self.psync_words = 4864   # (one-group sweeps: [0, 848); two-group forms: [1024, 4352); the reduce-scatter sweep's
+        #                           "gathered" words of its single-buffered exchange: [4352, 4864))
         self.bptt_rearmed = False                # the prologue of this step's forward has zeroed the BPTT sweep's words too
         # optional diagnostic stamps of the sweep launches / ticks (StepEngine.enable_trace), passed per call
         self.trace_fwd: Optional[torch.Tensor] = None

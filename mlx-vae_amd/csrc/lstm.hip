@@ -941,6 +941,9 @@ constexpr int PS_BWD = 512;                                  // the BPTT sweeps'
 // launch of a step (a block's group = parity of its arrival on its CU; each launch adds two arrivals per CU).
 constexpr int PS2_FWD_FLAGS = 1024, PS2_FWD_CNT = 1536, PS2_BWD_FLAGS = 1552, PS2_BWD_CNT = 2064, PS2_CU = 2304;
 constexpr int PS2_WORDS = PS2_CU + 8 * 256;                  // 4352: what a two-group step re-arms (arcvae_enc_prologue)
+// "gathered" words of the reduce-scatter BPTT sweep's single-buffered exchange: [NG][8 XCDs][32], the tick whose partial sums a
+// CU has finished reading (lstm_bwd_persist_rs_kernel, PersistRsArgs::parmask = 0)
+constexpr int PS3_DONE = PS2_WORDS, PS3_WORDS = PS3_DONE + 512;   // 4864
 struct PersistArgs {
     const int32_t* x_tb;
     const float* table0;
@@ -1237,6 +1240,10 @@ __global__ __launch_bounds__(256, NG) void lstm_fwd_persist_kernel(PersistArgs a
                 const int t = s - l;
                 const bool act = t >= 0 && t < T;
                 const unsigned off = (unsigned)(((long)mrow * H + 64 * wave + 4 * cg) * 4);
+                // (All 32 CUs of the XCD read the same 24 KB per tick and 32 readers per line queue at that line's L2 channel:
+                // 0.80 us from issue to landed.  Measured and dropped: the exchanged h ALSO stored in 2 / 4 / 8 replicas, a CU
+                // reading replica role % R -- the loads land in 0.56-0.60 us, the extra stores give it back: 0.982 / 0.992 /
+                // 1.014 ms per step against 0.983.)
                 if (act && l > 0) {
                     const __amdgpu_buffer_rsrc_t rs = ps_rsrc(a.hseq + (l - 1) * lH + (long)t * sH, sH * 4);
                     qx[l][0] = ps_load_sc1_x4(rs, off);
@@ -1249,6 +1256,10 @@ __global__ __launch_bounds__(256, NG) void lstm_fwd_persist_kernel(PersistArgs a
                 }
             }
             PS_STAMP(2);
+#ifdef ARCVAE_PS_STAMPS   // diagnostic build: when have the operand loads LANDED (forces the wait; slot 4 = the barrier otherwise)
+            if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            PS_STAMP(4);
+#endif
             // ---- rank-1 updates: for every k of my quarter, the A values of block (k >> 2) & 7 broadcast to its row group
 #pragma unroll
             for (int l = 0; l < LL; ++l) {
@@ -1348,7 +1359,9 @@ __global__ __launch_bounds__(256, NG) void lstm_fwd_persist_kernel(PersistArgs a
         }
         PS_STAMP(3);
         __syncthreads();
+#ifndef ARCVAE_PS_STAMPS
         PS_STAMP(4);
+#endif
         // ---- cell update of my (row, unit) pairs; c stays in a register from tick to tick.  (Storing the saved gates
         // and c after the flag, under the next tick's barrier wait, was measured twice: no gain without the store wait
         // below, 0.5 % slower with it -- 1.083-1.085 vs 1.077-1.078 ms per step.)
@@ -1686,7 +1699,8 @@ struct PersistRsArgs {
     float* dtable;            // [V,4H] token-table gradient workspace
     int V;
     int fw_dbg;               // timing experiments only (ARCVAE_FW_DEBUG): 1 no h loads, 2 no products, 4 no token table
-    int parmask;              // 1: the exchange buffers alternate with the tick's parity (0: timing experiments only -- a race)
+    int parmask;              // 1: the exchange buffers alternate with the tick's parity; 0: ONE buffer, guarded by `done`
+    unsigned* done;           // parmask = 0: [NG][8 XCDs][32] "tick whose partial sums this CU has finished gathering" words
 };
 
 // MF = 1 (registers only): the contraction on v_mfma_f32_4x4x1 (16 blocks of 4x4, K = 1) instead of 16x16x4.  An XCD owns
@@ -1715,7 +1729,9 @@ struct PersistRsArgs {
 // instructions per wave and tick, no padded rows), each half's partial sums into that half's exchange buffer, gather and
 // epilogue per half as in the RG = 2 walk.  NG = 2: the two-group form (see lstm_fwd_persist_kernel): 512 blocks, two per
 // CU, the XCD's up to 32 rows as two independent R16 recurrences with their own flag lines and exchange buffers.
-template <int LL, bool WR, int MF, bool FW = false, int RG = 1, int NG = 1>   // WR: the weight slices live in registers, else in LDS
+// SB = true: the single-buffered exchange (see `single` below; compiled in only where it is used -- its poll and check cost the
+// default shape's tick 0.35 us when they were a run-time branch of every variant).
+template <int LL, bool WR, int MF, bool FW = false, int RG = 1, int NG = 1, bool SB = false>   // WR: the weight slices live in registers, else in LDS
 __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsArgs ar) {
     static_assert(MF == 0 || WR, "the 4x4x1 form keeps its weights in registers");
     static_assert(!FW || MF == 1, "fused weight gradients: 4x4x1 form only");
@@ -1897,9 +1913,31 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
     const long part_src = (long)8 * 32 * 32 * 64;     // floats per (parity, source)
     float* const part_grp = ar.part + (long)grp * RG * 2 * S * part_src;   // two-group form: each group its own exchange buffers
     if constexpr (NG == 2) ps_stagger(grp, a.stagger);
+    // Single-buffered exchange (ar.parmask == 0): half the footprint in the XCD's L2 -- at 32 rows per XCD the two parities
+    // of the exchange are 6 MB against 4 MB of L2 and every gather missed (tick 10.0 -> 7.6 us isolated).  What the parity
+    // bought is restored by a second flag line: a CU raises done[role] = s + 1 behind the tick's closing barrier (all its
+    // gathers of tick s have returned); a producer looks at the 32 done words at the TOP of tick s + 1 and checks them just
+    // before its first partial store -- they were raised a whole product phase earlier, so the check costs no time.
+    constexpr bool single = SB;
+    unsigned* my_done = single ? ar.done + (grp * 8 + xcc) * 32 + role : nullptr;
+    const unsigned* xdone = single ? ar.done + (grp * 8 + xcc) * 32 : nullptr;
+    auto wait_gathered = [&](unsigned dv, int s) {    // every consumer of my XCD has finished reading tick s - 1
+        unsigned spins = 0;
+        while (!__all((int)(dv - (unsigned)s) >= 0)) {
+            if (++spins > 4000000u || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (lane == 0) atomicAdd(a.err, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            dv = (lane < 32) ? __hip_atomic_load(xdone + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)s;
+        }
+    };
 
     for (int s = a.s_begin; s < a.s_end; ++s) {
         PS_STAMP(0);
+        unsigned dv = (unsigned)s;                                // single buffer: the consumers' "gathered" words, requested now
+        if constexpr (SB) { if (lane < 32) dv = __hip_atomic_load(xdone + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        bool may_store = !SB;
         const int skew = 2 * (LL - 1 - el);
         const int t = is_cell ? T - 1 - (s - skew) : T - 1 - (s + 1 - skew);
         const bool jact = slot < S && t >= 0 && t < T;
@@ -1940,7 +1978,7 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
         if (s > a.s_begin) wg_prepare(s - 1, 0, 2);   // FW (sources 0, 1; source 2 behind the flag store): operands of the weight-gradient products of the previous tick's gate gradients
         PS_STAMP_START();
         // ---- partial products of the S slots from my local gate gradients; wave w covers units [64w, 64w + 64)
-        float* pbase = part_grp + (long)(s & ar.parmask) * S * part_src + (long)xcc * 32 * 32 * 64;   // 8-row half g: + g * 2 S part_src
+        float* pbase = part_grp + (long)(SB ? 0 : (s & 1)) * S * part_src + (long)xcc * 32 * 32 * 64;   // 8-row half g: + g * 2 S part_src
 #pragma unroll
         for (int g = 0; g < (R16 ? 1 : RG); ++g)   // (R16: both halves in one pass of 16-row tiles)
 #pragma unroll
@@ -1983,12 +2021,14 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
                             acc[ch][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF == 1 ? 2 : 0)], bq[k4].z, acc[ch][0], 0, 0, 0);
                             acc[ch][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[sj][sc][sk + (MF == 1 ? 3 : 0)], bq[k4].w, acc[ch][1], 0, 0, 0);
                         }
+                    if constexpr (SB) { if (!may_store) { wait_gathered(dv, s); may_store = true; } }
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch)   // unit chunk ch: units + 32 -> consumer + 4
                         *reinterpret_cast<f32x4*>(pdst + (long)ch * 4 * 32 * 64) =
                             f32x4{acc[ch][0].x + acc[ch][1].x, acc[ch][0].y + acc[ch][1].y,
                                   acc[ch][0].z + acc[ch][1].z, acc[ch][0].w + acc[ch][1].w};
                 } else {
+                    if constexpr (SB) { if (!may_store) { wait_gathered(dv, s); may_store = true; } }
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch)
                         *reinterpret_cast<f32x4*>(pdst + (long)ch * 4 * 32 * 64) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2025,6 +2065,7 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
             // scatter: rows 0..7 (lanes with r < 8; tile form: all 16 rows of every tile, each 8-row half into its own
             // buffers); a lane holds 4 consecutive units ju0.. of its row -> consumer ju0>>3, piece [row][ju0&7 ..]: one
             // 16-byte store per tile (4 per slot instead of 16 dword stores)
+            if constexpr (SB) { if (!may_store) { wait_gathered(dv, s); may_store = true; } }
             if (R16 || r < 8) {
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
@@ -2122,6 +2163,7 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
         }
         PS_STAMP(6);
         __syncthreads();
+        if constexpr (SB) { if (tid == 0) __hip_atomic_store(my_done, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
         PS_STAMP_END();
     }
     if constexpr (FW) {
@@ -2477,8 +2519,9 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
     if (chunk_index == 0 && !(flags & 1)) {   // flags bit 0: the words were zeroed ahead of the step (arcvae_enc_prologue)
-        const int rc = two ? arcvae_zero(reinterpret_cast<float*>(sync_ws + PS2_BWD_FLAGS), 1, PS2_CU - PS2_BWD_FLAGS, PS2_CU - PS2_BWD_FLAGS, stream)
-                           : arcvae_zero(reinterpret_cast<float*>(sync_ws + PS_BWD), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+        int rc = two ? arcvae_zero(reinterpret_cast<float*>(sync_ws + PS2_BWD_FLAGS), 1, PS2_CU - PS2_BWD_FLAGS, PS2_CU - PS2_BWD_FLAGS, stream)
+                     : arcvae_zero(reinterpret_cast<float*>(sync_ws + PS_BWD), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+        if (rc == ARCVAE_OK) rc = arcvae_zero(reinterpret_cast<float*>(sync_ws + PS3_DONE), 1, 512, 512, stream);   // the "gathered" words
         if (rc != ARCVAE_OK) return rc;
     }
     PersistRsArgs ar;
@@ -2499,7 +2542,12 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     for (int i = 0; i < 2 * L - 1; ++i) if (!ar.W[i]) return ARCVAE_ERR_ARG;
     ar.part = part_ws;
     ar.fw_dbg = arcvae_env_int("ARCVAE_FW_DEBUG", 0);
-    ar.parmask = arcvae_env_int("ARCVAE_DEBUG_RS_PARMASK", 1) & 1;
+    // ARCVAE_RS_SINGLE=0: two parities also from 17 rows per XCD on (there they are 6 MB against the XCD's 4 MB of L2; the
+    // single-buffered form, guarded by the "gathered" words, is the default: isolated tick 10.0 -> 7.9 us)
+    const int single_env = arcvae_env_int("ARCVAE_RS_SINGLE", -1);
+    const bool single = !fused && single_env != 0 && rows_x > 16;     // (compiled for the 32-row tile form only)
+    ar.parmask = single ? 0 : 1;
+    ar.done = sync_ws + PS3_DONE;
     ar.hseq = nullptr; ar.x_tb = nullptr; ar.dW[0] = ar.dW[1] = ar.dW[2] = nullptr; ar.dbias1 = nullptr; ar.dtable = nullptr; ar.V = 0;
     if (fused) {
         if (!fused->hseq || !fused->x_tb || !fused->dWx || !fused->dWh || !fused->dbias || !fused->dtable || fused->V < 1 ||
@@ -2532,7 +2580,15 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     // The tile form for 9..32 rows per XCD (ARCVAE_RS_R16=0: the 4x4x1 blocks walking groups of 8 rows): all rows of the XCD
     // in ONE pass of 16x16x4 tiles with full rows -- isolated tick 4.0 vs 5.4 us at 16 rows per XCD (bs 128)
     if (rgn >= 2 && !(flags & ARCVAE_PERSIST_BF16) && arcvae_env_int("ARCVAE_RS_R16", 1) != 0) {
+        // (the 32-row form holds more than 256 registers per lane: two of its blocks can never share a SIMD, so it needs no
+        // LDS floor to land one per CU -- and what it does not allocate stays with the GEMM blocks beside it;
+        // ARCVAE_RS_R32_LDS_KB > 0 restores a floor)
+        if (rgn == 4) {
+            const size_t need = sizeof(float) * (size_t)rgn * (L * 16 * 32 + 128), kb = (size_t)arcvae_env_int("ARCVAE_RS_R32_LDS_KB", 0) * 1024;
+            lds = need > kb ? need : kb;
+        }
         if (rgn == 2) { if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 0, false, 2>); else launch(lstm_bwd_persist_rs_kernel<2, true, 0, false, 2>); }
+        else if (single) { if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 0, false, 4, 1, true>); else launch(lstm_bwd_persist_rs_kernel<2, true, 0, false, 4, 1, true>); }
         else { if (L == 1) launch(lstm_bwd_persist_rs_kernel<1, true, 0, false, 4>); else launch(lstm_bwd_persist_rs_kernel<2, true, 0, false, 4>); }
         return arcvae_launch_status();
     }
