@@ -22,6 +22,7 @@ GEMM_BF16 = 256      # throughput mode: bf16 operands, f32 accumulate (include/a
 GEMM_SPLIT3 = 512    # three bf16 pieces per operand, six products: fp32-class accuracy (ARCVAE_GEMM_SPLIT3)
 LSTM_RETILE = 1      # arcvae_enc_lstm_backward flags
 LSTM_BF16 = 2        # arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime)
+LSTM_SPLIT3 = 4      # same places: three bf16 pieces per operand, six products -- a parity path (tiled regime)
 PERSIST_BF16 = 2     # arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags: throughput mode (4x4x4 bf16 blocks)
 DEC_BF16 = 256       # arcvae_dec_forward_dense mode bit / arcvae_dec_backward_dense flags bit
 DEC_SPLIT3 = 512     # same places: three-piece (fp32-class) products

@@ -83,8 +83,9 @@ class Workspace:
         self.hseq = torch.empty(L, T, B, H, **f32)
         RS = int(os.environ.get("ARCVAE_RING", "16"))  # ring slots over t (csrc/common.h: arcvae_ring_slots)
         RS = T if (RS <= 0 or RS > T) else RS
-        self.hseq_t = torch.empty(L, RS, B * H, **f32)     # k-chunk-major copy of h_t in slot t % RS (next launch's operand)
-        self.wt = torch.empty(2 * L - 1, G * H, **f32)        # k-chunk-major weights (forward layout)
+        # (x 3/2: in their three-piece form the register-tiled sweeps keep these copies as three bf16 planes, 6 bytes per value)
+        self.hseq_t = torch.empty(L, RS, B * H * 3 // 2, **f32)     # k-chunk-major copy of h_t in slot t % RS (next launch's operand)
+        self.wt = torch.empty(2 * L - 1, G * H * 3 // 2, **f32)        # k-chunk-major weights (forward layout)
         self.cseq = torch.empty(L, T, B, H, **f32)
         self.gseq = torch.empty(L, T, B, G, **f32)
         self.comb = torch.empty(B, 2 * H, **f32)
@@ -124,10 +125,10 @@ class Workspace:
             # written IN PLACE over the saved gates (same thread, after it has read them), and everything only the
             # next BPTT launch consumes lives in short rings over t (csrc/lstm.hip, common.h: arcvae_ring_slots).
             self.dG = self.gseq if os.environ.get("ARCVAE_INPLACE_DG", "1") != "0" else torch.empty(L, T, B, G, **f32)
-            self.dG_t = torch.empty(L, RS, B * G, **f32)      # k-chunk-major copy of dG_t in slot t % RS
+            self.dG_t = torch.empty(L, RS, B * G * 3 // 2, **f32)      # k-chunk-major copy of dG_t in slot t % RS
             self.dcs = torch.empty(L, RS, B, H, **f32)
             self.dxs = torch.empty(L, RS, B, H, **f32)
-            self.wT = torch.empty(2 * L - 1, H, G, **f32)
+            self.wT = torch.empty(2 * L - 1, H * G * 3 // 2, **f32)
             self.dtables = torch.zeros(2, V, G, **f32)        # both token tables: one zero fill (arcvae_enc_prologue)
             self.dtable0 = self.dtables[0]
             self.dtable1 = self.dtables[1]                    # the last chunk's token table, folded by the main stream itself
@@ -141,6 +142,15 @@ class Workspace:
             self.ddG = torch.empty(BV, G, **f32)
             self.dtableD = torch.empty(V, G, **f32)
             self.wcpart = torch.empty(V, G, max(Cc, 1), **f32)
+
+
+def _lstm_flags(ws) -> int:
+    """Precision of the launch-based sweeps where they run on the register-tiled kernels (the MFMA-bound regime): throughput
+    mode -> bf16 operands; else the three-piece form (three bf16 pieces per operand, six products: fp32-class accuracy at
+    6/16 of the exact-f32 matrix time; ARCVAE_LSTM_SPLIT3=0: exact-f32 MFMA)."""
+    if ws.bf16_parts & 1:
+        return _lib.LSTM_BF16
+    return _lib.LSTM_SPLIT3 if os.environ.get("ARCVAE_LSTM_SPLIT3", "1") != "0" else 0
 
 
 def _oct(ws, name: str) -> C.c_void_p:
@@ -211,7 +221,7 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         call("arcvae_enc_lstm_forward_persistent", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq),
              ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wT) if need_wT else C.c_void_p(0), ptr(ws.comb), ptr(ws.psync),
              start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L,
-             1 | (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0), ptr(ws.trace_fwd), s)
+             1 | (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0) | (_lstm_flags(ws) & _lib.LSTM_SPLIT3), ptr(ws.trace_fwd), s)
     else:
         comb_ready = 0
         if zero_grad:
@@ -224,7 +234,7 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         if start_signal is not None:
             call("arcvae_gate_set", start_signal, 1, 1, s)
         call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
-             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, _lib.LSTM_BF16 if ws.bf16_parts & 1 else 0,
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, _lstm_flags(ws),
              _oct(ws, "h_oct"), ptr(ws.trace_fwd), s)
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
@@ -483,7 +493,7 @@ class EncoderBackwardPlan:
             return
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
              2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
-             _lib.LSTM_BF16 if ws.bf16_parts & 1 else 0,  # no LSTM_RETILE: the forward of this step already wrote the BPTT weight layouts
+             _lstm_flags(ws),  # no LSTM_RETILE: the forward of this step already wrote the BPTT weight layouts
              _oct(ws, "dG_oct"), start_signal if start_signal is not None else C.c_void_p(0), ptr(ws.trace_bwd), stream_ptr())
 
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3, table=None) -> None:
@@ -616,7 +626,10 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     # outputs): two grouped launches in flight.  With the four chunks of the launch-based sweep this was 1 % slower
     # (1.084-1.088 vs 1.073 ms); with the two late chunks of the persistent sweep it is what makes them pay
     # (ARCVAE_WX_ON_SIDE=0/1 overrides).
-    wx_on_side = table_on_side and os.environ.get("ARCVAE_WX_ON_SIDE", "1" if plan.persistent else "0") != "0"
+    # (round 3: also with the mid-batch step kernels from 256 rows per GPU on -- bs 256: 3.081 -> 3.042 ms, bs 512: 6.47 -> 6.27;
+    # no difference at 160 / 192 rows)
+    mid_batch = ws is not None and ws.B >= 256 and not (_lib.load().arcvae_enc_lstm_tiled(ws.B, plan.d.H, plan.d.L) & 2)
+    wx_on_side = table_on_side and os.environ.get("ARCVAE_WX_ON_SIDE", "1" if (plan.persistent or mid_batch) else "0") != "0"
     # Round 2: the token-table path is linear, so every chunk folds its OWN table (zero, one-hot GEMM, fold: first = last
     # = True) -- and the LAST chunk's, the only one in the exposed tail, is formed by main itself right behind the sweep
     # (main is idle there and needs no gate for its own sweep), in parallel with the last dWx on side and dWh on aux:

@@ -342,12 +342,75 @@ __device__ __forceinline__ void tile_contract_b(f32x4 (&acc)[MT][NT], const __bf
     }
 }
 
+// ---- three-piece form (ARCVAE_LSTM_SPLIT3: a PARITY path): every f32 operand value as hi + mid + lo bf16 (8 + 8 + 8 bits),
+// the six products of weight >= 2^-16 on v_mfma_f32_16x16x32_bf16, f32 accumulate -- fp32-class accuracy (the split GEMMs of
+// gemm.hip have carried it since round 2) at 6/16 of the exact-f32 matrix time.  The operand copies are THREE bf16 planes of
+// the throughput mode's 32-wide k-chunk-major layout ([plane][kc][row][32]; a plane = rows * K elements), written by the step
+// epilogues (activations, gate gradients) and by arcvae_tile_weights modes 4 / 5 (weights).  6 bytes per value instead of 4:
+// a 64 x 64 wave tile moves 16 B per matrix cycle and wave -- the CU's 64 B/clk from L2 with its four waves -- so the
+// contraction sits where L2 delivery and the matrix pipe meet.
+__device__ __forceinline__ void split3_bf16(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = to_bf16(x);
+    const float r1 = x - (float)hi;
+    mid = to_bf16(r1);
+    lo = to_bf16(r1 - (float)mid);
+}
+template <int MT, int NT>
+struct TileFragS {
+    u32x4_l a[3][MT];
+    u32x4_l w[3][NT];
+};
+template <int MT, int NT>
+__device__ __forceinline__ void tile_load_s(TileFragS<MT, NT>& f, const __bf16* __restrict__ At, long planeA, const int* arow,
+                                            int RA, const __bf16* __restrict__ Wt, long planeW, const int* wrow, int RW, int kc,
+                                            int q8) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            f.a[p][m] = *reinterpret_cast<const u32x4_l*>(At + p * planeA + ((long)kc * RA + arow[m]) * 32 + q8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            f.w[p][n] = *reinterpret_cast<const u32x4_l*>(Wt + p * planeW + ((long)kc * RW + wrow[n]) * 32 + q8);
+    }
+}
+template <int MT, int NT, int NS>
+__device__ __forceinline__ void tile_contract_s(f32x4 (&acc)[MT][NT], const __bf16* __restrict__ At, long planeA,
+                                                const int* arow, int RA, const __bf16* __restrict__ Wt, long planeW,
+                                                const int* wrow, int RW, int nch, int q8) {
+    TileFragS<MT, NT> f[NS];
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nch) tile_load_s<MT, NT>(f[s], At, planeA, arow, RA, Wt, planeW, wrow, RW, s, q8);
+    for (int kc0 = 0; kc0 < nch; kc0 += NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int kn = kc0 + s + NS - 1;
+            if (kn < nch) tile_load_s<MT, NT>(f[(s + NS - 1) % NS], At, planeA, arow, RA, Wt, planeW, wrow, RW, kn, q8);
+            if (kc0 + s < nch) {
+                // products in ascending weight: hi.lo, lo.hi, mid.mid, hi.mid, mid.hi, hi.hi (pieces 0 = hi, 1 = mid, 2 = lo)
+#define TILE_S3(PA, PW)                                                                                              \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < NT; ++n)        \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_l, f[s].a[PA][m]),  \
+                                                                        __builtin_bit_cast(bf16x8_l, f[s].w[PW][n]),  \
+                                                                        acc[m][n], 0, 0, 0);
+                TILE_S3(0, 2) TILE_S3(2, 0) TILE_S3(1, 1) TILE_S3(0, 1) TILE_S3(1, 0) TILE_S3(0, 0)
+#undef TILE_S3
+            }
+        }
+    }
+}
+
 // Forward: wave tile = 16*MT rows x 16*NT gate columns (4*NT hidden units); block = 4 waves side by side =
 // 16*MT rows x 64*NT columns.  grid (H / (16*NT), ceil(B / (16*MT)), jobs).  The pre-activations go through a
 // per-wave LDS tile so that one lane gets the four gates of one (row, unit); then the same fused cell update as
 // lstm_fwd_step_kernel.  (MT, NT) = (4, 4): 16 FLOP per byte, one block per CU at configs[2].
-template <int MT, int NT, bool BF = false>
-__global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
+#ifndef ARCVAE_S3_LBF
+#define ARCVAE_S3_LBF 1
+#endif
+template <int MT, int NT, int P = 0>   // P: 0 exact-f32 MFMA, 1 throughput mode (bf16 operands), 2 three-piece bf16 (parity path)
+__global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_tile_kernel(FwdArgs a) {
+    constexpr bool BF = P == 1, S3 = P == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDT = 16 * NT + 1;     // LDS tile row stride
     constexpr int UW = 4 * NT;           // hidden units per wave
@@ -372,7 +435,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (BF) {   // throughput mode: bf16 operand copies, 32-wide chunks (H % 64 == 0)
+    if constexpr (S3) {   // three bf16 planes per operand, six products per 32-wide chunk
+#ifndef ARCVAE_S3_NS_FWD
+#define ARCVAE_S3_NS_FWD 2
+#endif
+        constexpr int NSS = (MT * NT >= 16) ? ARCVAE_S3_NS_FWD : ARCVAE_S3_NS_FWD + 1;
+        const int q8 = (lane >> 4) * 8;
+        const long pA = (long)B * H, pW = (long)G * H;
+        if (j.xin) tile_contract_s<MT, NT, NSS>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
+                                                reinterpret_cast<const __bf16*>(j.Wx), pW, wrow, G, H >> 5, q8);
+        if (j.hprev) tile_contract_s<MT, NT, NSS>(acc, reinterpret_cast<const __bf16*>(j.hprev), pA, arow, B,
+                                                  reinterpret_cast<const __bf16*>(j.Wh), pW, wrow, G, H >> 5, q8);
+    } else if constexpr (BF) {   // throughput mode: bf16 operand copies, 32-wide chunks (H % 64 == 0)
         constexpr int NSB = (MT * NT >= 16) ? 4 : 6;
         const int q8 = (lane >> 4) * 8;
         if (j.xin && !(a.dbg & 1)) tile_contract_b<MT, NT, NSB>(acc, reinterpret_cast<const __bf16*>(j.xin), arow, B,
@@ -442,7 +516,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
             float* gp = j.gates + (long)row * G + unit;
             gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
             j.h[hb] = hv;
-            if constexpr (BF) {
+            if constexpr (S3) {
+                __bf16 p0, p1, p2;
+                split3_bf16(hv, p0, p1, p2);
+                __bf16* tp = reinterpret_cast<__bf16*>(j.ht) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
+                const long pl = (long)B * H;
+                tp[0] = p0; tp[pl] = p1; tp[2 * pl] = p2;
+            } else if constexpr (BF) {
                 const __bf16 hb16 = to_bf16(hv);
                 reinterpret_cast<__bf16*>(j.ht)[((long)(unit >> 5) * B + row) * 32 + (unit & 31)] = hb16;
                 if (j.oct) reinterpret_cast<__bf16*>(j.oct)[((long)(row >> 3) * H + unit) * 8 + (row & 7)] = hb16;
@@ -457,8 +537,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_tile_kernel(FwdArgs a) {
 
 // BPTT: block = 16*MT rows x 128 hidden units (wave w: units [32w, 32w+32)), K = 4H.  grid (ceil(H/128),
 // ceil(B / (16*MT)), jobs).  An accumulator element IS one (row, unit): the cell epilogue runs on the registers.
-template <int MT, bool BF = false>
-__global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
+#ifndef ARCVAE_S3_LB
+#define ARCVAE_S3_LB 1
+#endif
+template <int MT, int P = 0>   // P as in lstm_fwd_tile_kernel
+__global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LB : 1)) void lstm_bwd_tile_kernel(BwdArgs a) {
+    constexpr bool BF = P == 1, S3 = P == 2;
     arcvae_set_prio(a.prio);
     const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     if (tr) a.trace[0] = wall_clock64();
@@ -481,7 +565,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (BF) {
+    if constexpr (S3) {
+#ifndef ARCVAE_S3_NS_BWD
+#define ARCVAE_S3_NS_BWD 2   /* two stages: a third (368 registers) was no faster alone and 9 % slower in the step -- the GEMMs beside the sweep lose their room */
+#endif
+        if (j.src) tile_contract_s<MT, 2, ARCVAE_S3_NS_BWD>(acc, reinterpret_cast<const __bf16*>(j.src), (long)B * G, arow, B,
+                                             reinterpret_cast<const __bf16*>(j.WT), (long)H * G, wrow, H, G >> 5, (lane >> 4) * 8);
+    } else if constexpr (BF) {
         if (j.src && !(a.dbg & 1)) tile_contract_b<MT, 2, 6>(acc, reinterpret_cast<const __bf16*>(j.src), arow, B,
                                              reinterpret_cast<const __bf16*>(j.WT), wrow, H, G >> 5, (lane >> 4) * 8);
     } else {
@@ -531,7 +621,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_kernel(BwdArgs a) {
             j.dcout[hb] = dc * f;
             float* dp = j.out + (long)row * G + unit;
             dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
-            if constexpr (BF) {
+            if constexpr (S3) {
+                __bf16* tp = reinterpret_cast<__bf16*>(j.outt) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
+                const long gs = (long)(H >> 5) * B * 32, pl = (long)B * G;
+                const float dv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __bf16 p0, p1, p2;
+                    split3_bf16(dv[q], p0, p1, p2);
+                    tp[q * gs] = p0; tp[q * gs + pl] = p1; tp[q * gs + 2 * pl] = p2;
+                }
+            } else if constexpr (BF) {
                 __bf16* tp = reinterpret_cast<__bf16*>(j.outt) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
                 const long gs = (long)(H >> 5) * B * 32;
                 const __bf16 b_i = to_bf16(d_i), b_f = to_bf16(d_f), b_g = to_bf16(d_g), b_o = to_bf16(d_o);
@@ -685,14 +785,14 @@ inline int choose_tile_mt(int B, int col_blocks, int jobs) {
     return 0;
 }
 
-template <int MT, int NT, bool BF = false>
+template <int MT, int NT, int P = 0>
 void launch_fwd_tile(const FwdArgs& a, int B, int H, int nj, hipStream_t s) {
     dim3 grid(H / (16 * NT), ceil_div(B, 16 * MT), nj);
-    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT, BF>), grid, dim3(256), 4 * 16 * MT * (16 * NT + 1) * sizeof(float), s, a);
+    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT, P>), grid, dim3(256), 4 * 16 * MT * (16 * NT + 1) * sizeof(float), s, a);
 }
-template <int MT, bool BF = false>
+template <int MT, int P = 0>
 void launch_bwd_tile(const BwdArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((lstm_bwd_tile_kernel<MT, BF>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((lstm_bwd_tile_kernel<MT, P>), grid, dim3(256), 0, s, a);
 }
 
 
@@ -2260,13 +2360,22 @@ static inline bool fwd_bf16(int B, int H, int L, int flags) { return (flags & AR
 static inline bool bwd_bf16(int B, int H, int L, int flags) {
     return (flags & ARCVAE_LSTM_BF16) && choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0;
 }
+// Three-piece form (ARCVAE_LSTM_SPLIT3, a parity path): where the sweep runs on the register-tiled kernels and the
+// throughput mode is not asked for.  The operand copies then hold three bf16 planes: 1.5 x the f32 copies' size.
+static inline bool fwd_split3(int B, int H, int L, int flags) {
+    return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) && fwd_tile_choice(B, H, L) != 0;
+}
+static inline bool bwd_split3(int B, int H, int L, int flags) {
+    return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) && choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0;
+}
 
 // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz; with wT_bwd also the BPTT layouts of
 // the same weights (keeps that launch off the chain between the sweeps) -- one launch for both when the 2(2L-1) jobs
 // fit (L <= 4)
+// fwd_p / bwd_p: 0 f32 copies, 1 bf16 (throughput mode), 2 three bf16 planes (slot stride 1.5 x the f32 copy's)
 static int tile_all_weights(const float* const* Wx, const float* const* Wh, float* wt, float* wT_bwd, int H, int L,
-                            bool fwd_b16, bool bwd_b16, hipStream_t stream) {
-    const long wsz = (long)H * 4 * H;
+                            int fwd_p, int bwd_p, hipStream_t stream) {
+    const long wsz0 = (long)H * 4 * H;
     const float* src[32];
     float* dst[32];
     int cols[32], mode[32];
@@ -2274,8 +2383,10 @@ static int tile_all_weights(const float* const* Wx, const float* const* Wh, floa
     for (int pass = 0; pass < (wT_bwd ? 2 : 1); ++pass) {
         float* base = pass == 0 ? wt : wT_bwd;
         if (!base) continue;                       // wt == null: only the BPTT layouts (persistent forward reads row-major)
+        const int pp = pass == 0 ? fwd_p : bwd_p;
+        const long wsz = pp == 2 ? wsz0 * 3 / 2 : wsz0;
         for (int l = 0; l < L; ++l) {
-            const int md = pass == 0 ? (fwd_b16 ? 2 : 0) : (bwd_b16 ? 3 : 1);
+            const int md = pass == 0 ? (pp == 2 ? 4 : (pp == 1 ? 2 : 0)) : (pp == 2 ? 5 : (pp == 1 ? 3 : 1));
             src[n] = Wh[l]; dst[n] = base + l * wsz; cols[n] = H; mode[n] = md; ++n;
             if (l > 0) { src[n] = Wx[l]; dst[n] = base + (L + l - 1) * wsz; cols[n] = H; mode[n] = md; ++n; }
         }
@@ -2317,10 +2428,12 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
-    const long wsz = (long)H * 4 * H;
-    const bool b16 = fwd_bf16(B, H, L, flags);
+    const bool b16 = fwd_bf16(B, H, L, flags), s3 = fwd_split3(B, H, L, flags);
+    const long wsz = s3 ? (long)H * 4 * H * 3 / 2 : (long)H * 4 * H;     // (three-piece form: three bf16 planes per copy)
+    const long sHt = s3 ? sH * 3 / 2 : sH;
     {
-        const int rc = tile_all_weights(Wx, Wh, wt, wT_bwd, H, L, b16, bwd_bf16(B, H, L, flags), stream);
+        const int rc = tile_all_weights(Wx, Wh, wt, wT_bwd, H, L, s3 ? 2 : (b16 ? 1 : 0),
+                                        bwd_split3(B, H, L, flags) ? 2 : (bwd_bf16(B, H, L, flags) ? 1 : 0), stream);
         if (rc != ARCVAE_OK) return rc;
     }
     const int tile_mt = fwd_tile_choice(B, H, L);
@@ -2336,25 +2449,32 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
             const int t = s - l;
             if (t < 0 || t >= T) continue;
             FwdJob& j = a.job[nj++];
-            j.xin = l > 0 ? hseq_t + ((long)(l - 1) * RS + (t % RS)) * sH : nullptr;
+            j.xin = l > 0 ? hseq_t + ((long)(l - 1) * RS + (t % RS)) * sHt : nullptr;
             j.Wx = l > 0 ? wt + (L + l - 1) * wsz : nullptr;
-            j.hprev = t > 0 ? hseq_t + ((long)l * RS + ((t - 1) % RS)) * sH : nullptr;
+            j.hprev = t > 0 ? hseq_t + ((long)l * RS + ((t - 1) % RS)) * sHt : nullptr;
             j.Wh = wt + l * wsz;
             j.pre = l > 0 ? bias[l] : table0;
             j.tok = l > 0 ? nullptr : x_tb + (long)t * B;
             j.cprev = t > 0 ? cseq + l * lH + (t - 1) * sH : nullptr;
             j.h = hseq + l * lH + t * sH;
-            j.ht = hseq_t + ((long)l * RS + (t % RS)) * sH;
+            j.ht = hseq_t + ((long)l * RS + (t % RS)) * sHt;
             j.c = cseq + l * lH + t * sH;
             j.gates = gseq + l * lG + t * sG;
             j.oct = oct ? static_cast<char*>(h_oct) + 2 * (l * lH + t * sH) : nullptr;
         }
         for (int k = nj; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
+        if (tile_mt && s3) {
+            if (tile_mt == 44) launch_fwd_tile<4, 4, 2>(a, B, H, nj, stream);
+            else if (tile_mt == 4) launch_fwd_tile<4, 2, 2>(a, B, H, nj, stream);
+            else if (tile_mt == 2) launch_fwd_tile<2, 2, 2>(a, B, H, nj, stream);
+            else launch_fwd_tile<1, 2, 2>(a, B, H, nj, stream);
+            continue;
+        }
         if (tile_mt && b16) {
-            if (tile_mt == 44) launch_fwd_tile<4, 4, true>(a, B, H, nj, stream);
-            else if (tile_mt == 4) launch_fwd_tile<4, 2, true>(a, B, H, nj, stream);
-            else if (tile_mt == 2) launch_fwd_tile<2, 2, true>(a, B, H, nj, stream);
-            else launch_fwd_tile<1, 2, true>(a, B, H, nj, stream);
+            if (tile_mt == 44) launch_fwd_tile<4, 4, 1>(a, B, H, nj, stream);
+            else if (tile_mt == 4) launch_fwd_tile<4, 2, 1>(a, B, H, nj, stream);
+            else if (tile_mt == 2) launch_fwd_tile<2, 2, 1>(a, B, H, nj, stream);
+            else launch_fwd_tile<1, 2, 1>(a, B, H, nj, stream);
             continue;
         }
         if (tile_mt) {
@@ -2394,7 +2514,9 @@ extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const flo
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
     int rc;
     if (wT_bwd) {      // BPTT layouts for a launch-based backward of the same step (the sweep itself reads row-major weights)
-        rc = tile_all_weights(Wx, Wh, nullptr, wT_bwd, H, L, false, false, stream);
+        // (in the precision the launch-based backward of this step will read them in: ADVICE r2)
+        rc = tile_all_weights(Wx, Wh, nullptr, wT_bwd, H, L, 0,
+                              bwd_split3(B, H, L, flags) ? 2 : (bwd_bf16(B, H, L, flags) ? 1 : 0), stream);
         if (rc != ARCVAE_OK) return rc;
     }
     if (!(flags & 1)) {   // bit 0: sync_ws was re-armed by arcvae_enc_prologue
@@ -2665,7 +2787,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                                         int L, int s_begin, int s_end, int flags, void* dG_oct, unsigned* start_signal,
                                         unsigned long long* trace, hipStream_t stream) {
     const int retile = flags & ARCVAE_LSTM_RETILE;
-    const bool b16 = bwd_bf16(B, H, L, flags);
+    const bool b16 = bwd_bf16(B, H, L, flags), s3 = bwd_split3(B, H, L, flags);
     const bool oct = b16 && dG_oct && (B % 16) == 0;
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
@@ -2674,7 +2796,8 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
     const long lH = (long)T * sH, lG = (long)T * sG;
-    const long wsz = (long)H * 4 * H;
+    const long wsz = s3 ? (long)H * 4 * H * 3 / 2 : (long)H * 4 * H;     // (three-piece form: three bf16 planes per copy)
+    const long sGt = s3 ? sG * 3 / 2 : sG;
     // tiled transposed weight copies: WhT[l] at wT + l*wsz, WxT[l] (l>=1) at wT + (L + l - 1)*wsz
     if (s_begin == 0 && retile) {
         const float* src[16];
@@ -2683,8 +2806,8 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         int n = 0;
         for (int l = 0; l < L; ++l) {
             if (!Wh[l] || (l > 0 && !Wx[l])) return ARCVAE_ERR_ARG;
-            src[n] = Wh[l]; dst[n] = wT + l * wsz; cols[n] = H; mode[n] = b16 ? 3 : 1; ++n;
-            if (l > 0) { src[n] = Wx[l]; dst[n] = wT + (L + l - 1) * wsz; cols[n] = H; mode[n] = b16 ? 3 : 1; ++n; }
+            src[n] = Wh[l]; dst[n] = wT + l * wsz; cols[n] = H; mode[n] = s3 ? 5 : (b16 ? 3 : 1); ++n;
+            if (l > 0) { src[n] = Wx[l]; dst[n] = wT + (L + l - 1) * wsz; cols[n] = H; mode[n] = s3 ? 5 : (b16 ? 3 : 1); ++n; }
         }
         const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
@@ -2705,7 +2828,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 BwdJob& j = a.job[nj++];
                 const bool top = (l == L - 1), last = (t == T - 1);
                 j.kind = 0;
-                j.src = last ? nullptr : dG_t + ((long)l * RS + ((t + 1) % RS)) * sG;
+                j.src = last ? nullptr : dG_t + ((long)l * RS + ((t + 1) % RS)) * sGt;
                 j.WT = wT + l * wsz;
                 if (top) { j.ext = last ? dh_top : nullptr; j.ext_ld = ld_dh_top; }
                 else { j.ext = dxs + ((long)l * RS + (t % RS)) * sH; j.ext_ld = H; }
@@ -2715,14 +2838,14 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 j.dcin = last ? nullptr : dcs + ((long)l * RS + ((t + 1) % RS)) * sH;
                 j.dcout = dcs + ((long)l * RS + (t % RS)) * sH;
                 j.out = dG + l * lG + t * sG;
-                j.outt = dG_t + ((long)l * RS + (t % RS)) * sG;
+                j.outt = dG_t + ((long)l * RS + (t % RS)) * sGt;
                 j.oct = oct ? static_cast<char*>(dG_oct) + 2 * (l * lG + t * sG) : nullptr;
             }
             const int tx = T - 1 - (s + 1 - skew);     // xproj_l(tx): feeds cell(l, tx) at the next launch
             if (l < L - 1 && tx >= 0 && tx < T) {
                 BwdJob& j = a.job[nj++];
                 j.kind = 1;
-                j.src = dG_t + ((long)(l + 1) * RS + (tx % RS)) * sG;
+                j.src = dG_t + ((long)(l + 1) * RS + (tx % RS)) * sGt;
                 j.WT = wT + (L + l) * wsz;             // WxT[l+1]
                 j.ext = nullptr; j.ext_ld = H;
                 j.gates = nullptr; j.c = nullptr; j.cprev = nullptr; j.dcin = nullptr; j.dcout = nullptr;
@@ -2739,10 +2862,16 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 hipLaunchKernelGGL(lstm_bwd_tile_ks_kernel, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 48 * 1024, stream, a);
                 continue;
             }
+            if (s3) {
+                if (tile_mt == 4) launch_bwd_tile<4, 2>(a, tgrid, stream);
+                else if (tile_mt == 2) launch_bwd_tile<2, 2>(a, tgrid, stream);
+                else launch_bwd_tile<1, 2>(a, tgrid, stream);
+                continue;
+            }
             if (b16) {
-                if (tile_mt == 4) launch_bwd_tile<4, true>(a, tgrid, stream);
-                else if (tile_mt == 2) launch_bwd_tile<2, true>(a, tgrid, stream);
-                else launch_bwd_tile<1, true>(a, tgrid, stream);
+                if (tile_mt == 4) launch_bwd_tile<4, 1>(a, tgrid, stream);
+                else if (tile_mt == 2) launch_bwd_tile<2, 1>(a, tgrid, stream);
+                else launch_bwd_tile<1, 1>(a, tgrid, stream);
                 continue;
             }
             if (tile_mt == 4) launch_bwd_tile<4>(a, tgrid, stream);

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(TrJobs j) {
 // mode 0 (forward):  W [4H, K] -> dst[(k/16)][perm(r)][k%16], perm(gate*H + unit) = (unit>>2)*16 + gate*4 + (unit&3)
 //                    (the 16 gate columns of a 4-unit forward block become 16 consecutive rows)
 // mode 1 (backward): W [4H, H] -> dst[(j/16)][unit][j%16]   (W^T, contraction index j = gate row, tiled)
+// modes 2 / 3: the same two layouts in bf16, 32-wide chunks (throughput mode); modes 4 / 5: as three bf16 planes (three-piece form)
 struct TileJobs {
     const float* src[16];
     float* dst[16];
@@ -81,6 +82,49 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(TileJobs j, int H) {
             const int rp = (unit >> 2) * 16 + gate * 4 + (unit & 3);
             *reinterpret_cast<float4*>(dst + ((long)(k >> 4) * 4 * H + rp) * 16 + (k & 15)) =
                 *reinterpret_cast<const float4*>(src + (long)r * K + k);
+        }
+        return;
+    }
+    if (j.mode[z] == 4 || j.mode[z] == 5) {
+        // three-piece form (ARCVAE_LSTM_SPLIT3): the layouts of modes 2 / 3 as THREE bf16 planes (hi, mid, lo: plane stride
+        // 4H * K elements) whose sum is the f32 weight to 2^-24 -- the operands of lstm.hip's tile_contract_s
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        auto bf = [](float x) { return __builtin_convertvector(f2v{x, 0.f}, b2v)[0]; };
+        auto pk2 = [](__bf16 a, __bf16 b) { return __builtin_bit_cast(unsigned, b2v{a, b}); };
+        __bf16* d16 = reinterpret_cast<__bf16*>(dst);
+        const long n8 = (long)4 * H * K / 8, plane = (long)4 * H * K;
+        const int k8n = K >> 3;
+        for (long i = (long)blockIdx.x * 256 + tid; i < n8; i += (long)gridDim.x * 256) {
+            float v[8];
+            long off;
+            if (j.mode[z] == 4) {      // forward layout: 8 consecutive k of a permuted row
+                const int r = (int)(i / k8n), k = (int)(i - (long)r * k8n) * 8;
+                const int gate = r / H, unit = r - gate * H;
+                const int rp = (unit >> 2) * 16 + gate * 4 + (unit & 3);
+                const float4 a = *reinterpret_cast<const float4*>(src + (long)r * K + k);
+                const float4 b = *reinterpret_cast<const float4*>(src + (long)r * K + k + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                off = ((long)(k >> 5) * 4 * H + rp) * 32 + (k & 31);
+            } else {                   // BPTT layout (transposed): 8 consecutive gate rows of one k
+                const int g0 = (int)(i / K) * 8, k = (int)(i % K);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = src[(long)(g0 + e) * K + k];
+                off = ((long)(g0 >> 5) * K + k) * 32 + (g0 & 31);
+            }
+            __bf16 p[3][8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p[0][e] = bf(v[e]);
+                const float r1 = v[e] - (float)p[0][e];
+                p[1][e] = bf(r1);
+                p[2][e] = bf(r1 - (float)p[1][e]);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<u4v*>(d16 + q * plane + off) =
+                    u4v{pk2(p[q][0], p[q][1]), pk2(p[q][2], p[q][3]), pk2(p[q][4], p[q][5]), pk2(p[q][6], p[q][7])};
         }
         return;
     }

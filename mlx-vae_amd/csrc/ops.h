@@ -17,6 +17,7 @@
 
 #define ARCVAE_LSTM_RETILE 1      /* arcvae_enc_lstm_backward flags: write the BPTT weight layouts first */
 #define ARCVAE_LSTM_BF16 2        /* arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime only) */
+#define ARCVAE_LSTM_SPLIT3 4      /* same places: three bf16 pieces per operand, six products (parity path; tiled regime only) */
 
 #define ARCVAE_PERSIST_BF16 2     /* arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags bit 1: throughput mode */
 #define ARCVAE_DEC_SPLIT3 512      /* same places: the B*V-row products with ARCVAE_GEMM_SPLIT3 (a parity path) */

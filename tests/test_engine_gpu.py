@@ -195,7 +195,7 @@ def test_step_other_hidden_sizes_and_depths(H, L, B, T, C):
 
 def test_unsupported_shapes_are_argument_errors():
     from arcvae_hip.engine import ModelDims
-    for kw in (dict(H=100), dict(H=576), dict(V=200), dict(C=9), dict(L=9)):
+    for kw in (dict(H=100), dict(H=576), dict(V=256), dict(V=1), dict(C=9), dict(L=9)):
         d = dict(V=80, E=16, H=64, Z=8, C=1, L=2)
         d.update(kw)
         with pytest.raises(ValueError):
