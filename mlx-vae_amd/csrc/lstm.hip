@@ -1315,7 +1315,13 @@ __global__ __launch_bounds__(256, NG) void lstm_fwd_persist_kernel(PersistArgs a
             }
         }
         if (s > 0) {   // every CU of my XCD has published tick s-1
-            if (wave == 0) {
+            // (polled by wave 1: waves 0 and 2 run the cell epilogues and have just requested next tick's gate terms -- a
+            // dependent token -> table-row pair of loads; the flag loads of a wave queue behind ITS older loads.  Forward
+            // sweep alone 419 -> 398 us at the default shape)
+#ifndef ARCVAE_FWD_POLL_WAVE
+#define ARCVAE_FWD_POLL_WAVE 1
+#endif
+            if (wave == ARCVAE_FWD_POLL_WAVE) {
                 unsigned spins = 0;
                 while (true) {
                     const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -2041,23 +2047,30 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
         const int skew = 2 * (LL - 1 - el);
         const int t = is_cell ? T - 1 - (s - skew) : T - 1 - (s + 1 - skew);
         const bool jact = slot < S && t >= 0 && t < T;
-        // forward values of my epilogue (static) -- requested first
+        // forward values of my epilogue (static).  ARCVAE_RS_LATE_PREFETCH = 0: requested first, at the top of the tick (they
+        // have landed by the gather); 1: requested behind the flag store, under the flag poll -- the products start at once
         float gi[RG], gf[RG], gg[RG], go[RG], c_v[RG], cprev_v[RG], ext_v[RG];
+        auto prefetch = [&]() {
 #pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            gi[g] = gf[g] = gg[g] = go[g] = c_v[g] = cprev_v[g] = ext_v[g] = 0.f;
-            if (eact[g] && is_cell && jact) {
-                const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb[g] * G + unit;
-                gi[g] = gp[0]; gf[g] = gp[H]; gg[g] = gp[2 * H]; go[g] = gp[3 * H];
-                c_v[g] = a.cseq[el * lH + (long)t * sH + hb[g]];
-                if (t > 0) cprev_v[g] = a.cseq[el * lH + (long)(t - 1) * sH + hb[g]];
-                if (el == LL - 1 && t == T - 1) ext_v[g] = a.dh_top[(long)eb[g] * a.ld_dh_top + unit];
-                if (s == a.s_begin) {
-                    dcst[g] = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb[g]] : 0.f;
-                    if (el < LL - 1) ext_v[g] = a.dxs[((long)el * RS + (t % RS)) * sH + hb[g]];
+            for (int g = 0; g < RG; ++g) {
+                gi[g] = gf[g] = gg[g] = go[g] = c_v[g] = cprev_v[g] = ext_v[g] = 0.f;
+                if (eact[g] && is_cell && jact) {
+                    const float* gp = a.gseq + el * lG + (long)t * sG + (long)eb[g] * G + unit;
+                    gi[g] = gp[0]; gf[g] = gp[H]; gg[g] = gp[2 * H]; go[g] = gp[3 * H];
+                    c_v[g] = a.cseq[el * lH + (long)t * sH + hb[g]];
+                    if (t > 0) cprev_v[g] = a.cseq[el * lH + (long)(t - 1) * sH + hb[g]];
+                    if (el == LL - 1 && t == T - 1) ext_v[g] = a.dh_top[(long)eb[g] * a.ld_dh_top + unit];
+                    if (s == a.s_begin) {
+                        dcst[g] = (t < T - 1) ? a.dcs[((long)el * RS + ((t + 1) % RS)) * sH + hb[g]] : 0.f;
+                        if (el < LL - 1) ext_v[g] = a.dxs[((long)el * RS + (t % RS)) * sH + hb[g]];
+                    }
                 }
             }
-        }
+        };
+#ifndef ARCVAE_RS_LATE_PREFETCH
+#define ARCVAE_RS_LATE_PREFETCH 1
+#endif
+        if constexpr (ARCVAE_RS_LATE_PREFETCH == 0 || FW) prefetch();
         int tok = 0;
         if constexpr (FW) {
             if (eact[0] && is_cell && jact && el == 0) tok = min(max(ar.x_tb[(long)t * B + eb[0]], 0), ar.V - 1);
@@ -2184,12 +2197,17 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
         PS_STAMP(3);
         __syncthreads();
         if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (ARCVAE_RS_LATE_PREFETCH != 0 && !FW) prefetch();
         // FW: the flags are travelling and the matrix pipe is idle: first part of the weight-gradient products
         if constexpr (LL > 1) { if (s > a.s_begin) wg_prepare(s - 1, 2, 3); }   // its loads fly while the flags are polled
         wg_mfma(0);
         if constexpr (LL > 1) wg_mfma(1);
-        // ---- every CU of my XCD has published its partials of tick s
-        if (wave == 0) {
+        // ---- every CU of my XCD has published its partials of tick s (polled by a wave without an epilogue job where there
+        // is one -- its flag loads then do not queue behind the epilogue's operand loads: ARCVAE_RS_POLL_WAVE)
+#ifndef ARCVAE_RS_POLL_WAVE
+#define ARCVAE_RS_POLL_WAVE 3
+#endif
+        if (wave == (S < 4 ? ARCVAE_RS_POLL_WAVE : 0)) {
             unsigned spins = 0;
             while (true) {
                 const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
