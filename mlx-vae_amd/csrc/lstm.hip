@@ -1468,7 +1468,10 @@ __global__ __launch_bounds__(256, NG) void lstm_fwd_persist_kernel(PersistArgs a
 #ifndef ARCVAE_PS_STAMPS
         PS_STAMP(4);
 #endif
-        // ---- cell update of my (row, unit) pairs; c stays in a register from tick to tick.  (Storing the saved gates
+        // ---- cell update of my (row, unit) pairs; c stays in a register from tick to tick.  (Round 3, measured and dropped: a
+        // pair on TWO adjacent lanes -- i, f and c on one, g, o and h on the other, the activation chain 2 transcendentals +
+        // tanh(c) deep instead of 5, all four waves busy: the forward sweep ALONE ran 398.7 -> 390.8 us, the step stayed at
+        // 0.970-0.972 ms: in the step the sweep's pace is set by the decoder's GEMMs beside it.)  (Storing the saved gates
         // and c after the flag, under the next tick's barrier wait, was measured twice: no gain without the store wait
         // below, 0.5 % slower with it -- 1.083-1.085 vs 1.077-1.078 ms per step.)
         const int te = s - el;
