@@ -2113,6 +2113,9 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
 #pragma unroll
                     for (int k4 = 0; k4 < 8; ++k4)
                         bq[k4] = *reinterpret_cast<const f32x4*>(dgl + g * DGL + (ls * 16 + 4 * rg + ij) * 32 + 4 * k4);
+                    // (round 3, measured and dropped: all eight LDS reads of a slot pinned in front of its first MFMA --
+                    // isolated tick 2.85 -> 2.95 us; the four accumulators in rotation, distance 4 instead of 2 -- 2.84: the
+                    // compiler's one-read-ahead schedule of this phase is not what holds it at 1.2 us)
                     f32x4 acc[2][2];      // two independent chains per unit chunk (first link: C = 0)
                     if constexpr (MF == 2) {
 #pragma unroll
