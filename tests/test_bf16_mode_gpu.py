@@ -47,6 +47,10 @@ CASES = [  # (cfg, B, T, env, forward sweep in bf16?)
     (O.Config(vocab_size=30, embedding_dim=32, hidden_dim=256, latent_dim=32, num_conditions=1, num_layers=1), 37, 9, {}, True),
     (O.Config(vocab_size=30, embedding_dim=32, hidden_dim=256, latent_dim=16, num_conditions=1, num_layers=2), 100, 10, {}, False),
     (O.Config(), 64, 128, {}, True),     # BASELINE.json configs[1]
+    # persistent FORWARD sweep + register-tiled bf16 BPTT (forced): the persistent forward writes the BPTT weight layouts
+    # in the precision the backward will read them in (they were always f32 -- silently wrong gradients)
+    (O.Config(vocab_size=24, embedding_dim=32, hidden_dim=128, latent_dim=16, num_conditions=1, num_layers=2), 64, 8,
+     {"ARCVAE_STEP_TILE": "2"}, False),
 ]
 
 

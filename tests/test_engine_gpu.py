@@ -230,12 +230,18 @@ def test_step_odd_vocabulary_and_embedding_sizes(V, E, Z, C, B, T):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("split3", ["1", "0"])     # three-piece bf16 form (round 3, the default) / exact-f32 MFMA
 @pytest.mark.parametrize("mt", [1, 2, 4, 44, 22])  # 44 = 64x64 forward wave tile, 22 = mid-batch 2x2 latency kernels
 @pytest.mark.parametrize("H,L,B,T,C", [(64, 2, 37, 6, 1), (192, 3, 70, 5, 2), (128, 1, 16, 4, 1), (256, 2, 130, 4, 1)])
-def test_tiled_large_batch_step_kernels(mt, H, L, B, T, C, monkeypatch):
+def test_tiled_large_batch_step_kernels(mt, H, L, B, T, C, split3, monkeypatch):
     """The register-tiled step kernels (lstm_fwd_tile_kernel / lstm_bwd_tile_kernel: the large-batch path,
     BASELINE.json configs[2]) forced on at small shapes: ragged row tiles, H not a multiple of 128 (idle waves in
-    the BPTT tile), single layer, every MT.  Same bar as the latency kernels: 1e-4 against the fp64 oracle."""
+    the BPTT tile), single layer, every MT -- in their three-piece bf16 form (ARCVAE_LSTM_SPLIT3, the default: hi / mid / lo
+    operand planes, six products) and on the exact-f32 MFMA.  Same bar as the latency kernels: 1e-4 against the fp64 oracle,
+    norm-wise and element-wise."""
+    if mt == 22 and split3 == "0":
+        pytest.skip("the 2x2 latency kernels have no three-piece form: one run covers them")
+    monkeypatch.setenv("ARCVAE_LSTM_SPLIT3", split3)
     monkeypatch.setenv("ARCVAE_STEP_TILE", str(mt))
     cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
     params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
@@ -260,6 +266,27 @@ def test_tiled_large_batch_step_kernels(mt, H, L, B, T, C, monkeypatch):
         else:
             assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)
     assert not bad, bad
+
+
+def test_three_piece_sweeps_have_f32_accuracy(monkeypatch):
+    """The three-piece form of the tiled sweeps is a PARITY path: its error against the fp64 oracle must be of the exact-f32
+    kernels' size, not bf16's -- hidden states and the recurrent weight gradient over a 24-step sweep at H 256 / L 2."""
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=256, latent_dim=16, num_conditions=1, num_layers=2)
+    B, T = 130, 24
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    monkeypatch.setenv("ARCVAE_STEP_TILE", "4")
+    errs = {}
+    for split3 in ("0", "1"):
+        monkeypatch.setenv("ARCVAE_LSTM_SPLIT3", split3)
+        eng, enc, dec = build_engine(cfg, params)
+        eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+        torch.cuda.synchronize()
+        errs[split3] = {n: rel_err(enc.g(n).cpu().numpy(), grads["encoder." + n])
+                        for n in ("lstm_layer_0.Wh", "lstm_layer_1.Wx", "lstm_layer_1.Wh", "embedding.weight")}
+    for n, e3 in errs["1"].items():
+        assert e3 < 3.0 * errs["0"][n] + 2e-6, (n, e3, errs["0"][n])      # (bf16 operands would sit at ~3e-3)
+        assert e3 < 2e-5, (n, e3)
 
 
 def test_config3_full_size_kernel_families_agree(monkeypatch):
