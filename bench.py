@@ -269,6 +269,10 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # (rehearsal on a one-GPU box: ARCVAE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 -- RCCL refuses two ranks per device, so
+    # it goes with ARCVAE_BENCH_BACKEND=gloo and ARCVAE_PERSIST=0; numbers from such a run mean nothing, the code path does)
+    if os.environ.get("ARCVAE_BENCH_ONE_DEVICE", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dp = world > 1 or args.force_dp
@@ -277,7 +281,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.force_dp:
             os.environ["ARCVAE_DP_FORCE_COLLECTIVES"] = "1"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("ARCVAE_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     global H, Z, L
     if args.config == "big":

@@ -24,3 +24,8 @@ cp(f"{G}/bf16_mode_{tag}.txt", f"{rnd}_bf16_mode.txt")
 cp(f"{G}/bf16_bench_{tag}.jsonl", f"{rnd}_bf16_bench.jsonl")
 cp(first(f"{G}/prof_bigb_{tag}/*/*_kernel_stats.csv"), f"{rnd}_bf16_big_kernel_stats.csv")
 cp(first(f"{G}/prof_defb_{tag}/*/*_kernel_stats.csv"), f"{rnd}_bf16_default_kernel_stats.csv")
+# round 3
+cp(first(f"{G}/prof_{tag}_big/*/*_kernel_stats.csv"), f"{rnd}_big_fp32_kernel_stats.csv")
+cp(first(f"{G}/prof_{tag}_sampler/*/*_kernel_stats.csv"), f"{rnd}_sampler_kernel_stats.csv")
+cp(first(f"{G}/prof_{tag}_shard/*/*_kernel_stats.csv"), f"{rnd}_shard256_kernel_stats.csv")
+cp(f"{G}/tick_stamps_{tag}.txt", f"{rnd}_tick_stamps.txt")

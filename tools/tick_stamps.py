@@ -8,6 +8,7 @@ BPTT stamps:    0 loop top | 1 epilogue operands requested | 2 products done, pa
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("ARCVAE_HIP_LIB", os.path.join(ROOT, "ab_libs", "libarcvae_stamps.so"))   # the diagnostic build
 for p in ("mlx-vae_amd", "tests", "oracle"): sys.path.insert(0, os.path.join(ROOT, p))
 import torch
 import arcvae_hip.engine as E
