@@ -457,7 +457,7 @@ def test_hypothesis_driven_shapes_full_step():
     from hypothesis import HealthCheck, given, settings, strategies as st
 
     @settings(max_examples=14, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
-    @given(V=st.integers(5, 127), E=st.sampled_from([4, 12, 16, 33, 64]), H=st.sampled_from([64, 128, 192, 256]),
+    @given(V=st.integers(5, 255), E=st.sampled_from([4, 12, 16, 33, 64]), H=st.sampled_from([64, 128, 192, 256]),
            Z=st.integers(1, 40), C=st.integers(1, 6), L=st.integers(1, 4), B=st.integers(1, 70), T=st.integers(1, 12),
            tf=st.sampled_from([0.0, 0.6, 1.0]), beta=st.sampled_from([0.0, 0.05, 0.4]), fb=st.sampled_from([0.0, 1.0]))
     def run(V, E, H, Z, C, L, B, T, tf, beta, fb):
