@@ -1,5 +1,5 @@
 """Repeat one training step (no update) many times and look for steps whose encoder gradients / gate gradients differ
-from the majority: frequency and location of an intermittent ordering error.  usage: python tools/race_hunt.py [N]"""
+from the majority: frequency and location of an intermittent ordering error.  usage: [RH_B=64 RH_T=12 RH_L=2] python tools/race_hunt.py [N]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,11 +8,11 @@ import torch
 import arcvae_oracle as O
 from helpers import HYPER, build_engine, make_case
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-H, L, B, T, C = 256, 2, 64, 12, 1
+H, L, B, T, C = 256, int(os.environ.get("RH_L", 2)), int(os.environ.get("RH_B", 64)), int(os.environ.get("RH_T", 12)), 1
 cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
 params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
 eng, enc, dec = build_engine(cfg, params)
-names = ["lstm_layer_0.Wh", "lstm_layer_1.Wh", "lstm_layer_0.bias", "lstm_layer_1.Wx", "embedding.weight"]
+names = ["lstm_layer_0.Wh", "lstm_layer_0.bias", "embedding.weight"] + [f"lstm_layer_{l}.{w}" for l in range(1, L) for w in ("Wh", "Wx")]
 ref, refdg, bad = None, None, []
 for it in range(N):
     eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)

@@ -1,5 +1,13 @@
 #!/bin/bash
-for cfg in "A=1" "ARCVAE_RS_MFMA=0" "ARCVAE_BPTT_CHUNKS=0.3,0.6,0.85,1.0" "ARCVAE_WX_ON_SIDE=0" "ARCVAE_INPLACE_DG=0" "ARCVAE_PERSIST_BWD=0" "ARCVAE_GATES=0" "ARCVAE_RS_WREG=0"; do
+# Repeats one training step per configuration and counts steps whose result differs from the first (tools/race_hunt.py):
+# every sweep form the engine can pick in round 3, at the batch sizes that select it.  Run on the GPU box; the output is
+# committed as profiles/r03_race_hunt.txt together with the commit it ran on.
+N=${1:-1500}
+for cfg in "RH_B=64" "RH_B=64 ARCVAE_RS_MFMA=0" "RH_B=64 ARCVAE_PERSIST_BWD=0" "RH_B=64 ARCVAE_GATES=0" "RH_B=64 ARCVAE_WX_ON_SIDE=0" \
+           "RH_B=37 RH_T=19" "RH_B=128" "RH_B=128 ARCVAE_RS_R16=0" "RH_B=128 ARCVAE_PERSIST2=0" "RH_B=100 RH_T=17" \
+           "RH_B=256" "RH_B=256 ARCVAE_PERSIST2=0" "RH_B=256 ARCVAE_RS_MAX_B=256 ARCVAE_PERSIST2=0" \
+           "RH_B=256 ARCVAE_RS_MAX_B=256 ARCVAE_PERSIST2=0 ARCVAE_RS_R16=0" "RH_B=200 RH_T=9 RH_L=1" \
+           "RH_B=512 RH_T=8 ARCVAE_LSTM_SPLIT3=0" "RH_B=512 RH_T=8"; do
   echo "== $cfg"
-  env $cfg timeout -k 10 100 python tools/race_hunt.py 1500 2>&1 | grep -v amdgpu.ids | tail -8
+  env $cfg timeout -k 10 150 python tools/race_hunt.py $N 2>&1 | grep -v amdgpu.ids | tail -8
 done
