@@ -102,6 +102,10 @@ int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const floa
 /* bit 0 / bit 1: the forward / backward sweep of this shape runs on the register-tiled step kernels, i.e. ARCVAE_LSTM_BF16
  * takes effect there and h_oct / dG_oct get written (pass them to arcvae_enc_lstm_wgrad only when both bits are set). */
 int arcvae_enc_lstm_tiled(int B, int H, int L);
+/* Time slots of the operand rings hseq_t [L,slots,..] / dG_t [L,slots,..] the sweeps use for this shape with these flags: T where
+ * the weight gradients read the operand planes (both sweeps on the three-piece tile kernels, B % 32 == 0: pass the rings to
+ * arcvae_enc_lstm_wgrad with parts bit 11), else min(T, 16).  The dc / dX rings always have min(T, 16) slots. */
+int arcvae_enc_lstm_operand_slots(int B, int T, int H, int L, int flags);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
  * position read by models/encoder.py:106.  dG out [L,T,B,4H] (may alias gseq: in-place); dG_t ws [L,RS,B*4H]; dcs, dxs
@@ -195,7 +199,9 @@ int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* W
  * runs behind the sweep, no sweep block is resident); bit 8 = dtable_ws was zeroed ahead of the call (arcvae_enc_prologue:
  * the zero-fill launch in front of a `first` range is skipped); bit 10 = the per-layer GEMMs as three-piece tile GEMMs
  * (ARCVAE_GEMM_SPLIT3: fp32-class accuracy, for the MFMA-bound regime beside the tiled sweeps); bit 7 = throughput mode (one bf16 product per GEMM step instead of
- * the six of the split form: not a parity path).  The token-table path is linear in dtable_ws, so a
+ * the six of the split form: not a parity path); bit 11 = h_oct / dG_oct are the sweeps' three-plane operand rings hseq_t /
+ * dG_t with ALL T time slots (arcvae_enc_lstm_operand_slots == T): the per-layer GEMMs read the planes directly (transposing
+ * LDS reads, no f32 loads, no re-splitting; needs B % 32 == 0).  The token-table path is linear in dtable_ws, so a
  * time range may be given its own workspace and both `first` and `last` (zero, accumulate, fold) on any stream. */
 int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0, const float* hseq,
                           const float* dG, float* dtable_ws, float* onehot_ws, float* dEmb, float* const* dWx,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "arcvae_transpose_tokens": [_vp, _vp, _i, _i, _vp],
     "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_lstm_tiled": [_i, _i, _i],
+    "arcvae_enc_lstm_operand_slots": [_i, _i, _i, _i, _i],
     "arcvae_enc_lstm_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_prologue": [_vp, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

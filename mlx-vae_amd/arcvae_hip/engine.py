@@ -70,6 +70,7 @@ class Workspace:
         self.B, self.T = B, T
         self.bf16 = False   # throughput mode (StepEngine(precision="bf16")): see StepEngine
         self.bf16_parts = 0
+        self.planes = False  # the weight-gradient GEMMs read the sweeps' operand planes (StepEngine.workspace)
         # inputs
         self.x = torch.zeros(B, T, **i32)
         self.x_tb = torch.zeros(T, B, **i32)
@@ -515,6 +516,15 @@ class EncoderBackwardPlan:
             # throughput mode: one bf16 product per GEMM step.  Not beside a persistent sweep: there the matrix pipe is
             # idle anyway and what counts is what fits on the sweep's SIMDs (measured at bs 64: 1.077 vs 1.03 ms)
             parts |= _lib.WGRAD_BF16
+        elif getattr(ws, "planes", False) and not self.persistent:
+            # MFMA-bound regime, three-piece sweeps: the GEMMs read the sweeps' operand planes (all T slots kept) -- see
+            # StepEngine.workspace; (| 16: the token-table one-hot GEMM keeps its exact-f32 tile form)
+            parts |= 2048 | 16
+            call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
+                 ptr(ws.hseq), ptr(ws.dG), ptr(table if table is not None else ws.dtable0), ptr(ws.onehot),
+                 ptr(enc.g("embedding.weight")), self._dwx[0], self._dwh[0], self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L,
+                 t_lo, t_hi, int(first), int(last), parts, ptr(ws.hseq_t), ptr(ws.dG_t), stream_ptr())
+            return
         elif (not self.persistent and os.environ.get("ARCVAE_WGRAD_SPLIT3", "1") != "0"
               and (_lib.load().arcvae_enc_lstm_tiled(ws.B, d.H, d.L) & 2)):
             # MFMA-bound regime (the BPTT runs on the register-tiled kernels): the weight-gradient GEMMs as three-piece tile
@@ -861,6 +871,20 @@ class StepEngine:
                 # bf16 copies of hseq / dG in the weight-gradient kernel's operand layout, written by the tiled sweeps
                 ws.h_oct = torch.zeros(self.d.L * T * B * self.d.H, dtype=torch.bfloat16, device=self.device)
                 ws.dG_oct = torch.zeros(self.d.L * T * B * 4 * self.d.H, dtype=torch.bfloat16, device=self.device)
+            # Operand rings of the launch-based sweeps: where both run on the three-piece tile kernels the library keeps ALL T time
+            # slots of the operand planes (arcvae_enc_lstm_operand_slots), and the weight-gradient GEMMs read those planes
+            # directly (arcvae_enc_lstm_wgrad parts bit 11: no f32 loads, no re-splitting) -- configs[2], the 2048-row leg
+            lib = _lib.load()
+            slots = lib.arcvae_enc_lstm_operand_slots(B, T, self.d.H, self.d.L, _lstm_flags(ws))
+            if slots > ws.hseq_t.shape[1]:
+                ws.hseq_t = torch.empty(self.d.L, slots, B * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
+                if train:
+                    ws.dG_t = torch.empty(self.d.L, slots, B * 4 * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
+            ws.planes = bool(train and slots == T and _lstm_flags(ws) == _lib.LSTM_SPLIT3 and B % 32 == 0
+                             and lib.arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3
+                             and os.environ.get("ARCVAE_WGRAD_PLANES", "1") != "0"
+                             and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)
+                             and lib.arcvae_enc_lstm_bwd_persistent_ok(B, T, self.d.H, self.d.L) != 1)
             self._ws[key] = ws
             self._probe_persistent(ws)
         return self._ws[key]

@@ -1000,6 +1000,23 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     // products, 64 x 64 tiles (61 KB of LDS).  For GEMMs that run BESIDE a persistent sweep: 2.7x less matrix-pipe time
     // than the exact-f32 form, in 32-cycle instead of 64-cycle instructions, on the SIMDs the chain's waves issue on.
     if ((flags & ARCVAE_GEMM_SPLIT3) && !(flags & ARCVAE_GEMM_BF16) && !(transA == 0 && M <= 256)) {
+        // 128 x 128 tiles (120 KB of LDS, ARCVAE_SPLIT3_TILE=128): half the operand bytes per output through L2 -> CU -- for the
+        // K-long weight-gradient shapes of the MFMA-bound regime, whose BPTT tile kernel holds no LDS
+        static const int tile3 = arcvae_env_int("ARCVAE_SPLIT3_TILE", 64);
+        if (tile3 == 128 && (flags & ARCVAE_GEMM_TILE128) && M >= 128 && N >= 128 && p.act == 0) {
+            dim3 g8(ceil_div(N, 128), ceil_div(M, 128), 1);
+            if (flags & ARCVAE_GEMM_SPLITK) {
+                static const int target8 = arcvae_env_int("ARCVAE_SPLIT3_BLOCKS", 256);
+                int z = min(ceil_div(target8, (int)(g8.x * g8.y)), max(1, K / 512));
+                if (z > 1) {
+                    p.kchunk = ceil_div(ceil_div(K, z), 64) * 64;
+                    g8.z = ceil_div(K, p.kchunk);
+                    if (!p.accumulate && arcvae_zero(C, M, N, ldc, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
+                }
+            }
+            if (launch_bf16_tile_t<128, 128, 32, 3>(p, g8, ak, bk, stream)) return arcvae_launch_status();
+            p.kchunk = ((K + BK - 1) / BK) * BK;
+        }
         dim3 grid(ceil_div(N, 64), ceil_div(M, 64), 1);
         if ((flags & ARCVAE_GEMM_SPLITK) && p.act == 0) {
             static const int target3 = arcvae_env_int("ARCVAE_SPLITK_BLOCKS", 512);
@@ -1156,7 +1173,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
         for (int i = 0; i < n; ++i) {
             if (K[i] <= 0) continue;
             const int rc = arcvae_gemm_f32(1, 0, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr,
-                                           ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_SPLIT3 | ARCVAE_GEMM_TILE64, stream);
+                                           ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_SPLIT3 | ARCVAE_GEMM_TILE64 | ARCVAE_GEMM_TILE128, stream);
             if (rc) return rc;
         }
         return colsums_by_launch();
@@ -1196,6 +1213,192 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
     hipLaunchKernelGGL((gemm_tile_group_kernel<64, 64, false, false, 4, 4>), grid, dim3(256), pad, stream, g);
     if (arcvae_launch_status() != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
     return colsums_by_launch();
+}
+
+// ---- weight gradients of the tiled three-piece sweeps, straight from the sweeps' operand planes (round 3) ------------------
+// In the MFMA-bound regime every dG and h value already exists as hi / mid / lo bf16 planes: the step epilogues write them as
+// the next launches' operands ([plane][col >> 5][row][32], csrc/lstm.hip).  Kept for ALL t (full-length rings) they are the
+// weight-gradient GEMM's operands too: dW[m][n] += sum over rows k of dG[k][m] . h[k][n] contracts over ROWS, and a 32-column
+// block of a plane is a row-major [row][32] image -- `ds_read_b64_tr_b16` hands a lane 4 consecutive rows of one column
+// (tools/probe_tr.hip shows the lane map), two of them are the 8 k of a 16x16x32 operand.  So: no f32 loads, no split on the
+// VALU (the three-piece tile GEMM splits every element once per tile that needs it: 8-32 times), no transposed copy; a K-step
+// is 24 contiguous 2 KB pieces moved global -> LDS by LDS-DMA.  Block = 128 (m: gate columns) x 128 (n: units), four waves of
+// 64 x 64, K-step = 32 rows of one time step, three LDS stages of 48 KB (two K-steps in flight).
+struct PlaneTN {
+    const __bf16* A;    // dG planes of the layer, slot of t = 0: [t][plane][M >> 5][rows][32]
+    const __bf16* B;    // h planes of the source layer:            [t][plane][N >> 5][rows][32]
+    float* C;           // [M, N] row-major, +=
+    int tA0, tB0;       // first time slot of each operand
+    int ksteps;         // (time steps) * (rows / 32)
+};
+#define ARCVAE_PLANE_GROUP_MAX 8
+struct PlaneTNGroup {
+    PlaneTN p[ARCVAE_PLANE_GROUP_MAX];
+    int n, M, N, rows, ldc, z;     // z = K slices per problem (atomic accumulation when > 1)
+};
+typedef short s16x4_g __attribute__((ext_vector_type(4)));
+struct PlaneFrag { s16x4_g lo, hi; };
+namespace {
+__global__ __launch_bounds__(256) void wgrad_planes_kernel(PlaneTNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];     // [3 stages][24 pieces: (operand, plane, column block)][32 rows][64 B]
+    constexpr int STAGE = 24 * 2048;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Blocks are dealt to the XCDs round-robin by linear id: hand XCD k a CONTIGUOUS range of the (problem, m tile, n tile) order,
+    // so that the 32 blocks it runs at a time are 8 m tiles x 4 n tiles of one problem -- every dG piece is fetched by 4 blocks
+    // and every h piece by 8 under ONE L2 (plain order: the blocks that share a dG piece sit on four different XCDs).
+    int bx, by, bz;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+        const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned xcd = id & 7, slot = id >> 3, q = n >> 3, r = n & 7;
+        const unsigned nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        bx = __builtin_amdgcn_readfirstlane((int)(nid % gx));
+        by = __builtin_amdgcn_readfirstlane((int)((nid / gx) % gy));
+        bz = __builtin_amdgcn_readfirstlane((int)(nid / (gx * gy)));
+    }
+    const int prob = __builtin_amdgcn_readfirstlane(bz / g.z), slice = bz - prob * g.z;
+    // the problem's fields once, into scalar registers: an ordinary load inside the K loop would make the compiler drain
+    // the LDS-DMA queue (vmcnt(0)) at its use
+    PlaneTN p;
+    {
+        const PlaneTN& q = g.p[prob];
+        // (readfirstlane returns a signed int: without the unsigned cast a low half with its top bit set sign-extends over the
+        // high half -- seen as a memory fault at 0xffff....)
+        auto uni64 = [](unsigned long long v) -> unsigned long long {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+            return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+        };
+        p.A = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.A)));
+        p.B = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.B)));
+        p.C = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.C)));
+        p.tA0 = __builtin_amdgcn_readfirstlane(q.tA0); p.tB0 = __builtin_amdgcn_readfirstlane(q.tB0);
+        p.ksteps = __builtin_amdgcn_readfirstlane(q.ksteps);
+    }
+    const int gM = g.M, gN = g.N, grows = g.rows;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int rb = grows >> 5;
+    const int per = (p.ksteps + g.z - 1) / g.z;
+    const int kbeg = slice * per, kend = min(p.ksteps, kbeg + per);
+    if (kbeg >= kend) return;                                           // block-uniform
+    const long planeA = (long)grows * gM, planeB = (long)grows * gN;
+    // loader: wave w moves pieces 6w .. 6w+5 of a stage, two 1 KB halves each (a lane: 16 bytes of row 16 hf + (lane >> 2)):
+    // ALWAYS 12 LDS-DMA instructions per wave and stage (the waits below count them; a column block beyond N repeats the last
+    // one, its image is never read).  The LDS image is lane-linear; the 16-byte octet a lane FETCHES is swizzled by its row's
+    // bit 3 so that the four 16-lane groups of a transposing read (rows 8 kq ..) fall on both halves of the banks.
+    auto issue = [&](int ks, int stage) {
+        const int t = ks / rb, b0 = (ks - t * rb) << 5;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int pc = 6 * wave + q, op = pc >= 12 ? 1 : 0, pl = (pc - 12 * op) >> 2, cb = pc & 3;
+            const int colblock = min(((op ? n0 : m0) >> 5) + cb, ((op ? gN : gM) >> 5) - 1);
+            const __bf16* src = op ? p.B + ((long)(p.tB0 + t) * 3 + pl) * planeB + ((long)colblock * grows + b0) * 32
+                                   : p.A + ((long)(p.tA0 + t) * 3 + pl) * planeA + ((long)colblock * grows + b0) * 32;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int row = 16 * hf + (lane >> 2), oct = (lane & 3) ^ (((row >> 3) & 1) << 1);
+                // (as assembly: for the builtin the compiler drains the whole LDS-DMA queue -- vmcnt(0) -- in front of the first LDS
+                // read that might alias it, i.e. every K-step; the counted waits below are the ordering)
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) char*)(pl_smem + stage * STAGE + pc * 2048 + hf * 1024));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src + row * 32 + oct * 8), "s"(dst) : "memory");
+            }
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool active = n0 + 64 * wn < gN;                               // wave-uniform
+    const int kq = lane >> 4, kp = (lane & 15) >> 2, a4 = lane & 3;
+    // transposing read: lane 4 kp + a4 of a 16-lane group supplies row 8 kq + 4 hh + kp, columns 16 tt2 + 4 a4 .. + 3 of the block
+    auto frag = [&](int stage, int op, int pl, int tt) -> bf16x8_t {
+        const int cb = 2 * (op ? wn : wm) + (tt >> 1), tt2 = tt & 1;
+        const char* base = pl_smem + stage * STAGE + ((op * 3 + pl) * 4 + cb) * 2048;
+        const int oct = (2 * tt2 + (a4 >> 1)) ^ ((kq & 1) << 1);
+        const char* q0 = base + (8 * kq + kp) * 64 + oct * 16 + (a4 & 1) * 8;
+        PlaneFrag f;
+        f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0));
+        f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0 + 4 * 64));
+        return __builtin_bit_cast(bf16x8_t, f);
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Three LDS stages, two K-steps in flight: a stage is read one barrier AFTER the counted wait that retires its LDS-DMA (each
+    // wave waits for its own 12, the barrier makes that true for all four), and re-filled one barrier after its last read.
+    issue(kbeg, 0);
+    if (kbeg + 1 < kend) issue(kbeg + 1, 1);
+    int cur = 0;
+    for (int ks = kbeg; ks < kend; ++ks) {
+        if (ks + 1 < kend) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ks + 2 < kend) issue(ks + 2, cur == 0 ? 2 : cur - 1);         // (the stage read at ks - 1)
+        if (active) {
+            bf16x8_t fa[3][4], fb[3][4];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    fa[pl][tt] = frag(cur, 0, pl, tt);
+                    fb[pl][tt] = frag(cur, 1, pl, tt);
+                }
+            // the six products of weight >= 2^-16, small ones first (pieces: 0 hi, 1 mid, 2 lo)
+#define PLANE_S3(PA, PB)                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
+            PLANE_S3(0, 2) PLANE_S3(2, 0) PLANE_S3(1, 1) PLANE_S3(0, 1) PLANE_S3(1, 0) PLANE_S3(0, 0)
+#undef PLANE_S3
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    if (!active) return;
+    // D[m = 4 (lane >> 4) + r][n = lane & 15] of tile (i, j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * wn + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + r;
+                float* c = p.C + (long)m * g.ldc + n;
+                if (g.z > 1) atomicAdd(c, acc[i][j][r]);
+                else *c += acc[i][j][r];
+            }
+        }
+}
+}  // namespace
+
+// dW_i[M, N] += dG_i^T . h_i over the time steps [t, t + nT) of each problem, operands = the sweeps' three-plane copies (all
+// time slots kept).  M % 128 == 0, N % 64 == 0, rows % 32 == 0.  Internal (ops.h).
+int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* A, const int* tA0, const void* const* B,
+                              const int* tB0, const int* nT, float* const* C, int ldc, hipStream_t stream) {
+    if (n <= 0 || n > ARCVAE_PLANE_GROUP_MAX || M <= 0 || N <= 0 || (M % 128) || (N % 64) || rows <= 0 || (rows % 32) || ldc < N)
+        return ARCVAE_ERR_ARG;
+    PlaneTNGroup g;
+    g.n = n; g.M = M; g.N = N; g.rows = rows; g.ldc = ldc;
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!A[i] || !B[i] || !C[i] || nT[i] <= 0 || tA0[i] < 0 || tB0[i] < 0) return ARCVAE_ERR_ARG;
+        PlaneTN& p = g.p[i];
+        p.A = static_cast<const __bf16*>(A[i]); p.B = static_cast<const __bf16*>(B[i]); p.C = C[i];
+        p.tA0 = tA0[i]; p.tB0 = tB0[i]; p.ksteps = nT[i] * (rows / 32);
+        kmax = max(kmax, p.ksteps);
+    }
+    for (int i = n; i < ARCVAE_PLANE_GROUP_MAX; ++i) g.p[i] = g.p[0];
+    const int tiles = (M / 128) * ceil_div(N, 128);
+    static const int target = arcvae_env_int("ARCVAE_PLANE_BLOCKS", 448);     // blocks wanted per launch
+    g.z = max(1, min(ceil_div(target, tiles * n), kmax / 16));                // at least 16 K-steps per slice
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24 * 2048);
+        attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_planes_kernel, dim3(ceil_div(N, 128), M / 128, n * g.z), dim3(256), 3 * 24 * 2048, stream, g);
+    return arcvae_launch_status();
 }
 
 // C_i[M,N] += A_i^T . B_i from octet-major bf16 operand copies (wgrad_octet_kernel), i < n <= 8, one launch.  Internal (ops.h).

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(FwdArgs a) {
     const FwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H;
-    const int bx = xcd_group_block(blockIdx.x, gridDim.x, a.remap);
+    const int bx = xcd_group_block(blockIdx.x, gridDim.x, a.remap & 1);
     const int r0 = blockIdx.y * 16, u0 = bx * 4;
     const int arow = min(r0 + (lane & 15), B - 1);
     const int jc = lane & 15;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_step_kernel(BwdArgs a) {
     const BwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
-    const int r0 = blockIdx.y * 16, u0 = xcd_group_block(blockIdx.x, gridDim.x, a.remap) * 16;
+    const int r0 = blockIdx.y * 16, u0 = xcd_group_block(blockIdx.x, gridDim.x, a.remap & 1) * 16;
     const int arow = min(r0 + (lane & 15), B - 1);
     const int wrow = u0 + (lane & 15);
     const bool cell = j.kind == 0;
@@ -360,10 +360,25 @@ struct TileFragS {
     u32x4_l a[3][MT];
     u32x4_l w[3][NT];
 };
+#ifndef ARCVAE_S3_SADDR
+#define ARCVAE_S3_SADDR 1
+#endif
+#ifndef ARCVAE_S3_RING2_FWD
+#define ARCVAE_S3_RING2_FWD 0
+#endif
+#ifndef ARCVAE_S3_RING2_BWD
+#define ARCVAE_S3_RING2_BWD 0
+#endif
+#ifndef ARCVAE_S3_RING2_KS
+#define ARCVAE_S3_RING2_KS 0
+#endif
 template <int MT, int NT>
 __device__ __forceinline__ void tile_load_s(TileFragS<MT, NT>& f, const __bf16* __restrict__ At, long planeA, const int* arow,
                                             int RA, const __bf16* __restrict__ Wt, long planeW, const int* wrow, int RW, int kc,
                                             int q8) {
+    // address = wave-uniform base (plane, chunk: scalar registers) + the lane's 32-bit offset (row, k octet): the loads take the
+    // scalar-base form and the ring carries MT + NT offsets instead of 3 (MT + NT) 64-bit pointers
+#if !ARCVAE_S3_SADDR
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -373,8 +388,21 @@ __device__ __forceinline__ void tile_load_s(TileFragS<MT, NT>& f, const __bf16* 
         for (int n = 0; n < NT; ++n)
             f.w[p][n] = *reinterpret_cast<const u32x4_l*>(Wt + p * planeW + ((long)kc * RW + wrow[n]) * 32 + q8);
     }
+    return;
+#endif
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const __bf16* ab = At + p * planeA + (long)kc * RA * 32;
+        const __bf16* wb = Wt + p * planeW + (long)kc * RW * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            f.a[p][m] = *reinterpret_cast<const u32x4_l*>(ab + (unsigned)(arow[m] * 32 + q8));
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            f.w[p][n] = *reinterpret_cast<const u32x4_l*>(wb + (unsigned)(wrow[n] * 32 + q8));
+    }
 }
-template <int MT, int NT, int NS>
+template <int MT, int NT, int NS, bool PIN = false>   // PIN: loads and products of a step stay in program order (register footprint)
 __device__ __forceinline__ void tile_contract_s(f32x4 (&acc)[MT][NT], const __bf16* __restrict__ At, long planeA,
                                                 const int* arow, int RA, const __bf16* __restrict__ Wt, long planeW,
                                                 const int* wrow, int RW, int nch, int q8) {
@@ -386,7 +414,9 @@ __device__ __forceinline__ void tile_contract_s(f32x4 (&acc)[MT][NT], const __bf
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int kn = kc0 + s + NS - 1;
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             if (kn < nch) tile_load_s<MT, NT>(f[(s + NS - 1) % NS], At, planeA, arow, RA, Wt, planeW, wrow, RW, kn, q8);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             if (kc0 + s < nch) {
                 // products in ascending weight: hi.lo, lo.hi, mid.mid, hi.mid, mid.hi, hi.hi (pieces 0 = hi, 1 = mid, 2 = lo)
 #define TILE_S3(PA, PW)                                                                                              \
@@ -399,6 +429,49 @@ __device__ __forceinline__ void tile_contract_s(f32x4 (&acc)[MT][NT], const __bf
             }
         }
     }
+}
+
+// The same contraction as a branch-free two-stage ring (nch even, >= 2: H % 64 == 0 makes every caller's count even).  The
+// generic ring's `if (kn < nch)` inside the unrolled body costs the register allocator its grip: it renames the stages across
+// the branches and shuttles the accumulators between AGPRs and VGPRs every iteration (456 registers for the 4 x 4 tile).
+template <int MT, int NT>
+__device__ __forceinline__ void tile_mfma_s(const TileFragS<MT, NT>& f, f32x4 (&acc)[MT][NT]) {
+#define TILE_S3(PA, PW)                                                                                              \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < NT; ++n)                    \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_l, f.a[PA][m]),                \
+                                                            __builtin_bit_cast(bf16x8_l, f.w[PW][n]), acc[m][n], 0, 0, 0);
+    TILE_S3(0, 2) TILE_S3(2, 0) TILE_S3(1, 1) TILE_S3(0, 1) TILE_S3(1, 0) TILE_S3(0, 0)
+#undef TILE_S3
+}
+template <int MT, int NT>
+__device__ __forceinline__ void tile_contract_s2(f32x4 (&acc)[MT][NT], const __bf16* __restrict__ At, long planeA,
+                                                 const int* arow, int RA, const __bf16* __restrict__ Wt, long planeW,
+                                                 const int* wrow, int RW, int nch, int q8) {
+    TileFragS<MT, NT> f0, f1;
+    tile_load_s<MT, NT>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, 0, q8);
+    for (int kc = 0; kc < nch - 2; kc += 2) {
+        tile_load_s<MT, NT>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 1, q8);
+        tile_mfma_s<MT, NT>(f0, acc);
+        tile_load_s<MT, NT>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 2, q8);
+        tile_mfma_s<MT, NT>(f1, acc);
+    }
+    tile_load_s<MT, NT>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, nch - 1, q8);
+    tile_mfma_s<MT, NT>(f0, acc);
+    tile_mfma_s<MT, NT>(f1, acc);
+}
+
+// Blocks are dealt to the XCDs round-robin by linear id, so the plain (x, y, job) order hands every XCD a slice of EVERY job:
+// 7 jobs' weight slices and 28 different row blocks go through each 4 MB L2 per launch (33 MB at configs[2], 264 MB over the
+// fabric).  mode bit 1 (ARCVAE_TILE_XCD): XCD k works on a CONTIGUOUS range of the (job, row block, column block) order --
+// one job's weights and rows, 12-20 MB per XCD, every weight slice shared by the XCD's row blocks under one L2.
+__device__ __forceinline__ void tile_xcd_block(int mode, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (!(mode & 2)) return;
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = id & 7, slot = id >> 3, q = n >> 3, r = n & 7;
+    const unsigned nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bx = (int)(nid % gx); by = (int)((nid / gx) % gy); bz = (int)(nid / (gx * gy));
 }
 
 // Forward: wave tile = 16*MT rows x 16*NT gate columns (4*NT hidden units); block = 4 waves side by side =
@@ -418,13 +491,15 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
     arcvae_set_prio(a.prio);
     const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     if (tr) a.trace[0] = wall_clock64();
-    const FwdJob& j = a.job[blockIdx.z];
+    int bx, by, bz;
+    tile_xcd_block(a.remap, bx, by, bz);
+    const FwdJob& j = a.job[bz];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
     const int r = lane & 15, q4 = (lane >> 4) * 4;
-    const int row0 = blockIdx.y * 16 * MT;
-    const int wcol0 = (blockIdx.x * 4 + wave) * 16 * NT;  // permuted weight rows: 16 consecutive = 4 units x (i,f,g,o)
-    const int ubase = (blockIdx.x * 4 + wave) * UW;       // first hidden unit of this wave
+    const int row0 = by * 16 * MT;
+    const int wcol0 = (bx * 4 + wave) * 16 * NT;  // permuted weight rows: 16 consecutive = 4 units x (i,f,g,o)
+    const int ubase = (bx * 4 + wave) * UW;       // first hidden unit of this wave
     int arow[MT], wrow[NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) arow[m] = min(row0 + 16 * m + r, B - 1);
@@ -442,10 +517,17 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
         constexpr int NSS = (MT * NT >= 16) ? ARCVAE_S3_NS_FWD : ARCVAE_S3_NS_FWD + 1;
         const int q8 = (lane >> 4) * 8;
         const long pA = (long)B * H, pW = (long)G * H;
+        if constexpr (NSS == 2 && ARCVAE_S3_RING2_FWD) {
+            if (j.xin) tile_contract_s2<MT, NT>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
+                                                reinterpret_cast<const __bf16*>(j.Wx), pW, wrow, G, H >> 5, q8);
+            if (j.hprev) tile_contract_s2<MT, NT>(acc, reinterpret_cast<const __bf16*>(j.hprev), pA, arow, B,
+                                                  reinterpret_cast<const __bf16*>(j.Wh), pW, wrow, G, H >> 5, q8);
+        } else {
         if (j.xin) tile_contract_s<MT, NT, NSS>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
                                                 reinterpret_cast<const __bf16*>(j.Wx), pW, wrow, G, H >> 5, q8);
         if (j.hprev) tile_contract_s<MT, NT, NSS>(acc, reinterpret_cast<const __bf16*>(j.hprev), pA, arow, B,
                                                   reinterpret_cast<const __bf16*>(j.Wh), pW, wrow, G, H >> 5, q8);
+        }
     } else if constexpr (BF) {   // throughput mode: bf16 operand copies, 32-wide chunks (H % 64 == 0)
         constexpr int NSB = (MT * NT >= 16) ? 4 : 6;
         const int q8 = (lane >> 4) * 8;
@@ -548,12 +630,14 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LB : 1)) void lstm_bwd_til
     if (tr) a.trace[0] = wall_clock64();
     if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const BwdJob& j = a.job[blockIdx.z];
+    int bx, by, bz;
+    tile_xcd_block(a.remap, bx, by, bz);
+    const BwdJob& j = a.job[bz];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
     const int r = lane & 15, q4 = (lane >> 4) * 4;
-    const int row0 = blockIdx.y * 16 * MT;
-    const int u0 = blockIdx.x * 128 + wave * 32;
+    const int row0 = by * 16 * MT;
+    const int u0 = bx * 128 + wave * 32;
     if (u0 >= H) return;                              // H not a multiple of 128: this wave has no units
     int arow[MT], wrow[2];
 #pragma unroll
@@ -569,8 +653,13 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LB : 1)) void lstm_bwd_til
 #ifndef ARCVAE_S3_NS_BWD
 #define ARCVAE_S3_NS_BWD 2   /* two stages: a third (368 registers) was no faster alone and 9 % slower in the step -- the GEMMs beside the sweep lose their room */
 #endif
-        if (j.src) tile_contract_s<MT, 2, ARCVAE_S3_NS_BWD>(acc, reinterpret_cast<const __bf16*>(j.src), (long)B * G, arow, B,
+        if constexpr (ARCVAE_S3_NS_BWD == 2 && ARCVAE_S3_RING2_BWD) {
+            if (j.src && !(a.dbg & 1)) tile_contract_s2<MT, 2>(acc, reinterpret_cast<const __bf16*>(j.src), (long)B * G, arow, B,
+                                               reinterpret_cast<const __bf16*>(j.WT), (long)H * G, wrow, H, G >> 5, (lane >> 4) * 8);
+        } else {
+        if (j.src && !(a.dbg & 1)) tile_contract_s<MT, 2, ARCVAE_S3_NS_BWD>(acc, reinterpret_cast<const __bf16*>(j.src), (long)B * G, arow, B,
                                              reinterpret_cast<const __bf16*>(j.WT), (long)H * G, wrow, H, G >> 5, (lane >> 4) * 8);
+        }
     } else if constexpr (BF) {
         if (j.src && !(a.dbg & 1)) tile_contract_b<MT, 2, 6>(acc, reinterpret_cast<const __bf16*>(j.src), arow, B,
                                              reinterpret_cast<const __bf16*>(j.WT), wrow, H, G >> 5, (lane >> 4) * 8);
@@ -578,7 +667,7 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LB : 1)) void lstm_bwd_til
         if (j.src) tile_contract<MT, 2, 4>(acc, j.src, arow, B, j.WT, wrow, H, G >> 4, q4);
     }
     const bool cell = j.kind == 0;
-    if constexpr (BF) { if (a.dbg & 2) { if (acc[0][0][0] == 12345.f) j.out[0] = 0.f; return; } }
+    if constexpr (BF || S3) { if (a.dbg & 2) { if (acc[0][0][0] == 12345.f) j.out[0] = 0.f; return; } }   // (timing experiments)
     // Epilogue per 16-row group m: the 8 (row, unit) elements of a lane are loaded together (clamped indices, no
     // branch between the loads) and only then computed and stored -- see the forward tile kernel.
 #pragma unroll
@@ -663,11 +752,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_ks_kernel(BwdArgs a) {
     if (tr) a.trace[0] = wall_clock64();
     if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const BwdJob& j = a.job[blockIdx.z];
+    int bx, by, bz;
+    tile_xcd_block(a.remap, bx, by, bz);
+    const BwdJob& j = a.job[bz];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
     const int r = lane & 15;
-    const int row0 = blockIdx.y * 64, u0 = blockIdx.x * 64;
+    const int row0 = by * 64, u0 = bx * 64;
     int arow[4], wrow[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -766,6 +857,147 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_ks_kernel(BwdArgs a) {
             if (j.oct && !(a.dbg & 8)) {
                 __bf16* op = reinterpret_cast<__bf16*>(j.oct) + ((long)(row >> 3) * G + unit) * 8 + (row & 7);
                 op[0] = b_i; op[(long)H * 8] = b_f; op[(long)2 * H * 8] = b_g; op[(long)3 * H * 8] = b_o;
+            }
+        }
+    }
+    if (tr) a.trace[1] = wall_clock64();
+}
+
+// BPTT, three-piece form, K split over the waves (round 3).  The 64 x 32 wave tile of lstm_bwd_tile_kernel<4, 2> asks its CU
+// for 96 B per matrix cycle (18 KB of operand planes per 768 cycles of MFMAs and wave) against the 64 B/clk the vector
+// memory path delivers, and its epilogue is bound by the NUMBER of memory instructions (25 per element: 2-byte plane stores,
+// 64-byte segments).  Here, as in lstm_bwd_tile_ks_kernel: a block owns 64 rows x 64 units, every wave contracts a quarter
+// of K = 4H into a 64 x 64 register tile (24 KB per 1536 matrix cycles: 64 B/clk per CU); ALL four partial tiles go through
+// LDS and come back in the epilogue's layout -- a lane owns FOUR ADJACENT units of a row, so every load and store of the
+// cell epilogue is 16 bytes per lane (8 for the bf16 planes) in whole 128-byte lines: 25 memory instructions per FOUR
+// elements.  grid (H/64, ceil(B/64), jobs), 64 KB of LDS.
+#ifndef ARCVAE_KS3_PIN
+#define ARCVAE_KS3_PIN 1
+#endif
+__global__ __launch_bounds__(256) void lstm_bwd_tile_ks3_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ksred[];     // [4 dst groups][4 src waves][4 n][4 regs][64 lanes]
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
+    if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int bx, by, bz;
+    tile_xcd_block(a.remap, bx, by, bz);
+    const BwdJob& j = a.job[bz];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H, G = 4 * a.H;
+    const int row0 = by * 64, u0 = bx * 64;
+    f32x4 mine[4];                                        // [reg: row 16 wave + 4 (lane >> 4) + reg][k: unit u0 + 4 (lane & 15) + k]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mine[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j.src && !(a.dbg & 1)) {                          // block-uniform (dbg: timing experiments only)
+        const int r = lane & 15;
+        int arow[4], wrow[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            arow[m] = min(row0 + 16 * m + r, B - 1);
+            wrow[m] = u0 + 16 * m + r;                    // (H % 64 == 0: always a unit)
+        }
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nq = G >> 7;                            // 32-wide chunks per wave (G / 32 / 4)
+        const __bf16* At = reinterpret_cast<const __bf16*>(j.src) + (long)wave * nq * B * 32;
+        const __bf16* Wt = reinterpret_cast<const __bf16*>(j.WT) + (long)wave * nq * H * 32;
+#if ARCVAE_S3_RING2_KS
+        tile_contract_s2<4, 4>(acc, At, (long)B * G, arow, B, Wt, (long)H * G, wrow, H, nq, (lane >> 4) * 8);
+#else
+        tile_contract_s<4, 4, 2>(acc, At, (long)B * G, arow, B, Wt, (long)H * G, wrow, H, nq, (lane >> 4) * 8);
+#endif
+        // every partial tile through LDS: group m of wave w -> slot [m][w]; element (n, reg) of lane = row 16 m + 4 (lane >> 4) + reg,
+        // unit u0 + 16 n + (lane & 15)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float* dst = ksred + ((m * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dst[(n * 4 + reg) * 64] = acc[m][n][reg];
+        }
+        __syncthreads();
+        // ... and back, transposed: my four adjacent units 4 (lane & 15) + k sit in tile n = (lane & 15) >> 2 at lanes
+        // (lane >> 4) * 16 + 4 (lane & 3) + k of the source wave: one 16-byte LDS read per (source, reg)
+        const int nL = (lane & 15) >> 2, l0 = (lane >> 4) * 16 + 4 * (lane & 3);
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ksred + ((wave * 4 + sw) * 16 + nL * 4 + reg) * 64 + l0);
+                mine[reg] += v;
+            }
+    }
+    const bool cell = j.kind == 0;
+    if (a.dbg & 2) { if (mine[0][0] == 12345.f) j.out[0] = 0.f; return; }
+    const int unit = u0 + 4 * (lane & 15);
+    // two rows per batch: all operand loads of a batch are issued before its first store
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        f32x4 gi[2], gf[2], gg[2], go[2], cv[2], cpv[2], dci[2], exv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = min(row0 + 16 * wave + (lane >> 4) * 4 + 2 * hf + e, B - 1);
+            const long hb = (long)row * H + unit;
+            exv[e] = j.ext ? *reinterpret_cast<const f32x4*>(j.ext + (long)row * j.ext_ld + unit) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cell) {
+                const float* gp = j.gates + (long)row * G + unit;
+                gi[e] = *reinterpret_cast<const f32x4*>(gp);
+                gf[e] = *reinterpret_cast<const f32x4*>(gp + H);
+                gg[e] = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+                go[e] = *reinterpret_cast<const f32x4*>(gp + 3 * H);
+                cv[e] = *reinterpret_cast<const f32x4*>(j.c + hb);
+                cpv[e] = j.cprev ? *reinterpret_cast<const f32x4*>(j.cprev + hb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                dci[e] = j.dcin ? *reinterpret_cast<const f32x4*>(j.dcin + hb) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = row0 + 16 * wave + (lane >> 4) * 4 + 2 * hf + e;
+            if (row >= B) continue;
+            const long hb = (long)row * H + unit;
+            const f32x4 dh = mine[2 * hf + e] + exv[e];
+            if (!cell) {
+                *reinterpret_cast<f32x4*>(j.out + hb) = dh;
+                continue;
+            }
+            f32x4 d_i, d_f, d_g, d_o, dcf;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float i = gi[e][k], f = gf[e][k], g = gg[e][k], o = go[e][k];
+                const float tc = tanhf(cv[e][k]);
+                d_o[k] = dh[k] * tc * o * (1.f - o);
+                const float dc = dh[k] * o * (1.f - tc * tc) + dci[e][k];
+                d_i[k] = dc * g * i * (1.f - i);
+                d_f[k] = j.cprev ? dc * cpv[e][k] * f * (1.f - f) : 0.f;
+                d_g[k] = dc * i * (1.f - g * g);
+                dcf[k] = dc * f;
+            }
+            *reinterpret_cast<f32x4*>(j.dcout + hb) = dcf;
+            float* dp = j.out + (long)row * G + unit;
+            *reinterpret_cast<f32x4*>(dp) = d_i;
+            *reinterpret_cast<f32x4*>(dp + H) = d_f;
+            *reinterpret_cast<f32x4*>(dp + 2 * H) = d_g;
+            *reinterpret_cast<f32x4*>(dp + 3 * H) = d_o;
+            // the three bf16 planes of the next launches' operand copy: 4 units = 8 bytes per (gate, plane)
+            __bf16* tp = reinterpret_cast<__bf16*>(j.outt) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
+            const long gs = (long)(H >> 5) * B * 32, pl = (long)B * G;
+            const f32x4 dv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __bf16 pc[3][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) split3_bf16(dv[q][k], pc[0][k], pc[1][k], pc[2][k]);
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz) {
+                    typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<bf16x4_l*>(tp + q * gs + pz * pl) = bf16x4_l{pc[pz][0], pc[pz][1], pc[pz][2], pc[pz][3]};
+                }
             }
         }
     }
@@ -910,7 +1142,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step2_kernel(FwdArgs a) {
     const FwdJob& j = a.job[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, H = a.H, G = 4 * a.H;
-    const int bx = xcd_group_block(blockIdx.x, gridDim.x, a.remap);  // 4 consecutive blocks fill a 128-B line of h / c
+    const int bx = xcd_group_block(blockIdx.x, gridDim.x, a.remap & 1);  // 4 consecutive blocks fill a 128-B line of h / c
     const int r0 = blockIdx.y * 32, u0 = bx * 8;
     // epilogue role first: thread -> (row = tid >> 3, unit = u0 + (tid & 7)); token -> table row is a dependent pair
     const int erow = tid >> 3, ul = tid & 7;
@@ -2392,6 +2624,15 @@ static inline bool fwd_split3(int B, int H, int L, int flags) {
 static inline bool bwd_split3(int B, int H, int L, int flags) {
     return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) && choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0;
 }
+// Operand-plane weight gradients (gemm.hip: wgrad_planes_kernel): both sweeps on the three-piece tile kernels and whole
+// 32-row K-steps.  The operand rings (hseq_t, dG_t) then keep ALL T time slots -- the planes a launch writes for the next
+// launch are the weight-gradient GEMM's operands as well; the small dc / dX rings stay short.  ARCVAE_WGRAD_PLANES=0: off.
+static inline bool wgrad_planes_mode(int B, int H, int L, int flags) {
+    return fwd_split3(B, H, L, flags) && bwd_split3(B, H, L, flags) && (B % 32) == 0 && arcvae_env_int("ARCVAE_WGRAD_PLANES", 1) != 0;
+}
+static inline int operand_ring_slots(int B, int T, int H, int L, int flags) {
+    return wgrad_planes_mode(B, H, L, flags) ? T : arcvae_ring_slots(T);
+}
 
 // tiled weights: Wh_t[l] at wt + l*wsz, Wx_t[l] (l >= 1) at wt + (L + l - 1)*wsz; with wT_bwd also the BPTT layouts of
 // the same weights (keeps that launch off the chain between the sweeps) -- one launch for both when the 2(2L-1) jobs
@@ -2425,6 +2666,13 @@ static int tile_all_weights(const float* const* Wx, const float* const* Wh, floa
 // bit 0: arcvae_enc_lstm_forward runs this shape on the register-tiled step kernels, bit 1: arcvae_enc_lstm_backward does
 // -- i.e. where ARCVAE_LSTM_BF16 takes effect (and the octet-major copies get written: both bits needed for the
 // weight-gradient kernel that reads them).
+// Time slots of the operand rings hseq_t / dG_t the sweeps will use for this shape and these flags (T when the weight
+// gradients read the operand planes, else the short ring of common.h): what the caller sizes those workspaces with.
+extern "C" int arcvae_enc_lstm_operand_slots(int B, int T, int H, int L, int flags) {
+    if (B <= 0 || T <= 0 || L <= 0 || !hidden_ok(H)) return 0;
+    return operand_ring_slots(B, T, H, L, flags);
+}
+
 extern "C" int arcvae_enc_lstm_tiled(int B, int H, int L) {
     if (B <= 0 || L <= 0 || !hidden_ok(H)) return 0;
     return (fwd_tile_choice(B, H, L) != 0 ? 1 : 0) | (choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0 ? 2 : 0);
@@ -2463,10 +2711,10 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     const int tile_mt = fwd_tile_choice(B, H, L);
     const bool oct = b16 && h_oct && (B % 16) == 0;      // the octet-major copy groups 8 batch rows of one time step
     const bool step2 = !tile_mt && choose_step2(B);
-    const int RS = arcvae_ring_slots(T);
+    const int RS = operand_ring_slots(B, T, H, L, flags);
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
-        a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace ? trace + 2 * (long)s : nullptr;
+        a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap() | (arcvae_env_int("ARCVAE_TILE_XCD", 0) != 0 ? 2 : 0); a.trace = trace ? trace + 2 * (long)s : nullptr;
         a.dbg = arcvae_env_int("ARCVAE_TILE_DEBUG", 0);
         int nj = 0;
         for (int l = 0; l < L; ++l) {
@@ -2838,10 +3086,10 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     }
     const int tile_mt = choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1);
     const bool step2 = !tile_mt && choose_step2(B);
-    const int RS = arcvae_ring_slots(T);
+    const int RS = arcvae_ring_slots(T), RSo = operand_ring_slots(B, T, H, L, flags);   // dc / dX rings, operand-plane ring
     for (int s = s_begin; s < s_end; ++s) {
         BwdArgs a;
-        a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap(); a.trace = trace ? trace + 2 * (long)s : nullptr;
+        a.B = B; a.H = H; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap() | (arcvae_env_int("ARCVAE_TILE_XCD", 0) != 0 ? 2 : 0); a.trace = trace ? trace + 2 * (long)s : nullptr;
         a.dbg = arcvae_env_int("ARCVAE_TILE_DEBUG", 0);
         a.signal = (s == s_begin) ? start_signal : nullptr;
         int nj = 0;
@@ -2852,7 +3100,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 BwdJob& j = a.job[nj++];
                 const bool top = (l == L - 1), last = (t == T - 1);
                 j.kind = 0;
-                j.src = last ? nullptr : dG_t + ((long)l * RS + ((t + 1) % RS)) * sGt;
+                j.src = last ? nullptr : dG_t + ((long)l * RSo + ((t + 1) % RSo)) * sGt;
                 j.WT = wT + l * wsz;
                 if (top) { j.ext = last ? dh_top : nullptr; j.ext_ld = ld_dh_top; }
                 else { j.ext = dxs + ((long)l * RS + (t % RS)) * sH; j.ext_ld = H; }
@@ -2862,14 +3110,14 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 j.dcin = last ? nullptr : dcs + ((long)l * RS + ((t + 1) % RS)) * sH;
                 j.dcout = dcs + ((long)l * RS + (t % RS)) * sH;
                 j.out = dG + l * lG + t * sG;
-                j.outt = dG_t + ((long)l * RS + (t % RS)) * sGt;
+                j.outt = dG_t + ((long)l * RSo + (t % RSo)) * sGt;
                 j.oct = oct ? static_cast<char*>(dG_oct) + 2 * (l * lG + t * sG) : nullptr;
             }
             const int tx = T - 1 - (s + 1 - skew);     // xproj_l(tx): feeds cell(l, tx) at the next launch
             if (l < L - 1 && tx >= 0 && tx < T) {
                 BwdJob& j = a.job[nj++];
                 j.kind = 1;
-                j.src = dG_t + ((long)(l + 1) * RS + (tx % RS)) * sGt;
+                j.src = dG_t + ((long)(l + 1) * RSo + (tx % RSo)) * sGt;
                 j.WT = wT + (L + l) * wsz;             // WxT[l+1]
                 j.ext = nullptr; j.ext_ld = H;
                 j.gates = nullptr; j.c = nullptr; j.cprev = nullptr; j.dcin = nullptr; j.dcout = nullptr;
@@ -2887,6 +3135,14 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 continue;
             }
             if (s3) {
+                // ARCVAE_BWD_KSPLIT3 (default 1; 2 forces it: tests): the K-split 64 x 64 three-piece form where its grid fills the chip (its
+                // 16-byte epilogue accesses need dh_top on a 16-byte grid)
+                const int ks3 = arcvae_env_int("ARCVAE_BWD_KSPLIT3", 1);   // (read per call: tests toggle it)
+                if (ks3 != 0 && (ks3 == 2 || (H / 64) * ceil_div(B, 64) * nj >= 200) && (ld_dh_top % 4) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dh_top) % 16) == 0) {
+                    hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 64 * 1024, stream, a);
+                    continue;
+                }
                 if (tile_mt == 4) launch_bwd_tile<4, 2>(a, tgrid, stream);
                 else if (tile_mt == 2) launch_bwd_tile<2, 2>(a, tgrid, stream);
                 else launch_bwd_tile<1, 2>(a, tgrid, stream);
@@ -2925,6 +3181,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   runs behind the sweep: no sweep block is resident, the 322-register tile fits);
 //   bit 4 = exact-f32 MFMA tile GEMMs instead of the split-bf16 kernel (45 instead of 208 registers per lane: what
 //   fits on a SIMD beside a persistent sweep wave of more than 296 registers, i.e. the 2 / 4 row-group sweeps)
+//   bit 11 = h_oct / dG_oct are the three-plane operand rings hseq_t / dG_t with all T slots: GEMMs from the planes
 //   onehot_ws [T*B, roundup(V,4)] workspace: one-hot token rows, written when `first` != 0 (token-table part)
 extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0,
                                      const float* hseq, const float* dG, float* dtable_ws, float* onehot_ws,
@@ -2971,7 +3228,28 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                     Cg[n] = dWx[l]; Sg[n] = dbias[l]; Kg[n] = nt * B; ++n;   // same rows as the bias sum: colsum(dG_l[t_lo..t_hi))
                 }
             }
-            if (b16 && h_oct && dG_oct && (B % 16) == 0) {
+            if ((parts & 2048) && h_oct && dG_oct) {
+                // bit 11: h_oct / dG_oct are the sweeps' three-plane operand rings with all T slots (arcvae_enc_lstm_operand_slots
+                // == T): the weight gradients straight from the planes (gemm.hip: wgrad_planes_kernel)
+                if ((B % 32) != 0 || (H % 64) != 0) return ARCVAE_ERR_ARG;
+                const void* Ap[2 * ARCVAE_MAX_LAYERS];
+                const void* Bp[2 * ARCVAE_MAX_LAYERS];
+                int ta[2 * ARCVAE_MAX_LAYERS], tb[2 * ARCVAE_MAX_LAYERS], nts[2 * ARCVAE_MAX_LAYERS];
+                for (int i = 0; i < n; ++i) {
+                    const long ao = Ag[i] - dG, bo = Bg[i] - hseq;                  // element offsets: (layer, t) of each operand
+                    const int la = (int)(ao / lG), lb = (int)(bo / lH);
+                    ta[i] = (int)((ao - la * lG) / ((long)B * G)); tb[i] = (int)((bo - lb * lH) / ((long)B * H));
+                    nts[i] = Kg[i] / B;
+                    Ap[i] = static_cast<const char*>(dG_oct) + 2 * ((long)la * T * 3 * B * G);
+                    Bp[i] = static_cast<const char*>(h_oct) + 2 * ((long)lb * T * 3 * B * H);
+                }
+                for (int i = 0; i < n; i += 8) {
+                    rc = arcvae_wgrad_planes_group(n - i < 8 ? n - i : 8, G, H, B, Ap + i, ta + i, Bp + i, tb + i, nts + i, Cg + i, H, stream);
+                    if (rc) return rc;
+                }
+                for (int i = 0; i < n; ++i)
+                    if (Sg[i]) { rc = arcvae_colsum_accum(Ag[i], Kg[i], G, G, Sg[i], 1.0f, stream); if (rc) return rc; }
+            } else if (b16 && h_oct && dG_oct && (B % 16) == 0) {
                 // throughput mode with the octet-major bf16 copies the tiled sweeps left (same ranges, same targets)
                 const void* Ao[2 * ARCVAE_MAX_LAYERS];
                 const void* Bo[2 * ARCVAE_MAX_LAYERS];

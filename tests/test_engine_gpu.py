@@ -268,6 +268,71 @@ def test_tiled_large_batch_step_kernels(mt, H, L, B, T, C, split3, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("H,L,B,T,C", [(64, 2, 37, 6, 1), (192, 3, 70, 5, 2), (128, 1, 16, 4, 1), (256, 2, 130, 4, 1)])
+def test_k_split_three_piece_bptt_tile(H, L, B, T, C, monkeypatch):
+    """lstm_bwd_tile_ks3_kernel (the BPTT tile of the MFMA-bound regime since round 3: 64 x 64 blocks, K split over the waves,
+    partial tiles through LDS, a lane owning four adjacent units in the epilogue) forced on at small shapes: ragged row
+    blocks, two-chunk K quarters (H 64), H not a multiple of 128, one layer.  1e-4 against the fp64 oracle, both metrics."""
+    monkeypatch.setenv("ARCVAE_STEP_TILE", "4")
+    monkeypatch.setenv("ARCVAE_BWD_KSPLIT3", "2")
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+        else:
+            assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("ks3", ["2", "0"])        # BPTT tile: K-split 64 x 64 form / 64 x 32 wave tile
+@pytest.mark.parametrize("H,L,B,T,C", [(64, 2, 64, 6, 1), (192, 3, 96, 5, 2), (192, 2, 160, 12, 1), (256, 2, 288, 4, 1), (320, 1, 32, 4, 1)])
+def test_operand_plane_weight_gradients(H, L, B, T, C, ks3, monkeypatch):
+    """MFMA-bound regime with whole 32-row K-steps (B % 32 == 0): the operand rings keep all T time slots of the three-piece
+    planes and the weight-gradient GEMMs read them directly (gemm.hip wgrad_planes_kernel: LDS-DMA staging, transposing LDS
+    reads, six bf16 products; single slice and K-sliced with atomics -- (192, 2, 160, 12)).  Forced on at small shapes that the
+    persistent sweeps do not take (H not a multiple of 128, or more than 256 rows); the
+    gradients must meet the oracle at 1e-4 in both metrics, and the engine must really have taken the plane path."""
+    monkeypatch.setenv("ARCVAE_STEP_TILE", "4")
+    monkeypatch.setenv("ARCVAE_BWD_KSPLIT3", ks3)
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    ws = eng.workspace(B, T, True)
+    assert ws.planes and ws.hseq_t.shape[1] == T and ws.dG_t.shape[1] == T
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+        else:
+            assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)
+    assert not bad, bad
+
+
 def test_three_piece_sweeps_have_f32_accuracy(monkeypatch):
     """The three-piece form of the tiled sweeps is a PARITY path: its error against the fp64 oracle must be of the exact-f32
     kernels' size, not bf16's -- hidden states and the recurrent weight gradient over a 24-step sweep at H 256 / L 2."""
