@@ -274,6 +274,8 @@ def main(argv=None):
     if os.environ.get("ARCVAE_BENCH_ONE_DEVICE", "0") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if os.environ.get("ARCVAE_BENCH_MAIN_PRIO", "0") == "1":   # experiment: the critical chain on a high-priority stream
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     dev = torch.device("cuda", local_rank)
     use_dp = world > 1 or args.force_dp
     if use_dp:

@@ -485,7 +485,7 @@ template <int MT, int NT, int P = 0>   // P: 0 exact-f32 MFMA, 1 throughput mode
 __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_tile_kernel(FwdArgs a) {
     constexpr bool BF = P == 1, S3 = P == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LDT = 16 * NT + 1;     // LDS tile row stride
+    constexpr int LDT = P == 2 ? 16 * NT + 4 : 16 * NT + 1;     // LDS tile row stride (three-piece form: 16-byte aligned rows for the quad epilogue)
     constexpr int UW = 4 * NT;           // hidden units per wave
     constexpr int NS = (MT * NT >= 16) ? 2 : 4;  // 4x4: a 4-stage ring (364 registers) measured no faster than 2
     arcvae_set_prio(a.prio);
@@ -554,6 +554,70 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
     // as the compiler knows, so a load placed after a store would wait for it, and the token -> table-row -> cell
     // chain would be paid once per pair in sequence.
     if constexpr (BF) { if (a.dbg & 2) return; }
+    if constexpr (S3) {
+        // Quad epilogue (round 3): a lane owns FOUR ADJACENT units of a row -- their 16 pre-activations are 64 contiguous bytes of
+        // the LDS tile (the permuted gate columns: 4 units x (i, f, g, o)), and every global access is 16 bytes per lane (8 for a
+        // bf16 plane): 14 memory instructions per four (row, unit) pairs instead of per pair.  16 MT NT quads per wave.
+        constexpr int NQ = 16 * MT * NT, QPL = (NQ + 63) / 64;
+        typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+        f32x4 pv[QPL][4], cpv[QPL];
+        int qrow[QPL], qunit[QPL];
+#pragma unroll
+        for (int it = 0; it < QPL; ++it) {
+            const int idx = min(it * 64 + lane, NQ - 1);
+            qrow[it] = row0 + idx / NT;
+            qunit[it] = ubase + 4 * (idx % NT);
+            const int rc = min(qrow[it], B - 1);
+            long o = 0;
+            if (j.tok) {
+                int tk = j.tok[rc];
+                tk = min(max(tk, 0), a.V - 1);
+                o = (long)tk * G;
+            }
+            const float* pre = j.pre + o + qunit[it];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pv[it][g] = *reinterpret_cast<const f32x4*>(pre + g * H);
+            cpv[it] = j.cprev ? *reinterpret_cast<const f32x4*>(j.cprev + (long)rc * H + qunit[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < QPL; ++it) {
+            const int idx = it * 64 + lane;
+            if (idx >= NQ) continue;
+            const int row = qrow[it], unit = qunit[it];
+            if (row >= B) continue;
+            const float* tp = t + (idx / NT) * LDT + 16 * (idx % NT);
+            const f32x4 vi = *reinterpret_cast<const f32x4*>(tp), vf = *reinterpret_cast<const f32x4*>(tp + 4),
+                        vg = *reinterpret_cast<const f32x4*>(tp + 8), vo = *reinterpret_cast<const f32x4*>(tp + 12);
+            f32x4 gi, gf, gg, go, cc, hv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gi[k] = sigmoidf_acc(vi[k] + pv[it][0][k]);
+                gf[k] = sigmoidf_acc(vf[k] + pv[it][1][k]);
+                gg[k] = tanhf(vg[k] + pv[it][2][k]);
+                go[k] = sigmoidf_acc(vo[k] + pv[it][3][k]);
+                cc[k] = j.cprev ? gf[k] * cpv[it][k] + gi[k] * gg[k] : gi[k] * gg[k];
+                hv[k] = go[k] * tanhf(cc[k]);
+            }
+            const long hb = (long)row * H + unit;
+            float* gp = j.gates + (long)row * G + unit;
+            *reinterpret_cast<f32x4*>(gp) = gi;
+            *reinterpret_cast<f32x4*>(gp + H) = gf;
+            *reinterpret_cast<f32x4*>(gp + 2 * H) = gg;
+            *reinterpret_cast<f32x4*>(gp + 3 * H) = go;
+            *reinterpret_cast<f32x4*>(j.h + hb) = hv;
+            *reinterpret_cast<f32x4*>(j.c + hb) = cc;
+            __bf16 pc[3][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) split3_bf16(hv[k], pc[0][k], pc[1][k], pc[2][k]);
+            __bf16* hp = reinterpret_cast<__bf16*>(j.ht) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
+            const long pl = (long)B * H;
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz)
+                *reinterpret_cast<bf16x4_l*>(hp + pz * pl) = bf16x4_l{pc[pz][0], pc[pz][1], pc[pz][2], pc[pz][3]};
+        }
+        if (tr) a.trace[1] = wall_clock64();
+        return;
+    }
     constexpr int NPAIR = MT * NT;
     constexpr int NP = NPAIR < 8 ? NPAIR : 8;
 #pragma unroll
@@ -1020,7 +1084,7 @@ inline int choose_tile_mt(int B, int col_blocks, int jobs) {
 template <int MT, int NT, int P = 0>
 void launch_fwd_tile(const FwdArgs& a, int B, int H, int nj, hipStream_t s) {
     dim3 grid(H / (16 * NT), ceil_div(B, 16 * MT), nj);
-    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT, P>), grid, dim3(256), 4 * 16 * MT * (16 * NT + 1) * sizeof(float), s, a);
+    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT, P>), grid, dim3(256), 4 * 16 * MT * (16 * NT + (P == 2 ? 4 : 1)) * sizeof(float), s, a);
 }
 template <int MT, int P = 0>
 void launch_bwd_tile(const BwdArgs& a, dim3 grid, hipStream_t s) {

@@ -1,13 +1,14 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/r3_big.sh TAG ["ENV=.." ...]
 # BASELINE.json configs[2] (H512 L4 bs 512) and the 2048-row strong leg under environment settings: ms/step, the BPTT tile
-# launch alone and in the step.
+# launch alone and in the step.  R3_ONLY="--config big" (or "--batch-per-gpu 2048"): that shape only.
 TAG=$1; shift
 OUT=gpurun_out/r3_big_$TAG
 mkdir -p $OUT
 for cfg in "" "$@"; do
   name=$(echo "${cfg:-auto}" | tr ' =' '__')
   for shape in "--config big" "--batch-per-gpu 2048"; do
+    if [ -n "$R3_ONLY" ] && [ "$shape" != "$R3_ONLY" ]; then continue; fi
     sn=$(echo "$shape" | tr ' -' '__')
     env $cfg timeout -k 10 300 python bench.py --cpu-steps 0 $shape --steps 8 --warmup 3 --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 --shard-steps 0 --sampler-reps 0 \
         > $OUT/bench_${name}${sn}.json 2> $OUT/bench_${name}${sn}.log || echo "FAILED $cfg $shape"
