@@ -717,7 +717,7 @@ def roofline_probe(eng, ws, torch):
 
     Dominant kernel of a training step at this shape = the BPTT sweep of the encoder stack, in whichever family the
     engine runs it (profiles/): lstm_bwd_persist_rs_kernel (persistent reduce-scatter sweep: up to 128 rows per GPU at
-    H 256, one launch per chunk, a "launch" below = one TICK of it), lstm_bwd_tile_kernel / lstm_bwd_tile_ks_kernel (the
+    H 256, one launch per chunk, a "launch" below = one TICK of it), lstm_bwd_tile_ks3_kernel / lstm_bwd_tile_kernel (the
     register-tiled step kernels of the MFMA-bound regime: bs 2048, configs[2]) or lstm_bwd_step / step2_kernel (per-step
     launches).  A tick / launch carries 2L-1 single-source jobs (L cell steps dG_{t+1} . Wh^T and L-1 input-gradient
     projections dG^{l+1}_t . Wx^T), each a [B,4H] x [4H,H] contraction = 2*B*4H*H FLOP.
@@ -774,7 +774,7 @@ def roofline_probe(eng, ws, torch):
     tiled = (not persistent) and bool(_lib_load().arcvae_enc_lstm_tiled(B, d.H, d.L) & 2)
     bf16 = getattr(eng, "precision", "fp32") == "bf16" and (persistent or tiled)   # the sweep really runs bf16 blocks / tiles
     kernel = ("lstm_bwd_persist_rs_kernel" if persistent else
-              ("lstm_bwd_tile_kernel / lstm_bwd_tile_ks_kernel" if tiled else
+              (("lstm_bwd_tile_ks_kernel" if bf16 else "lstm_bwd_tile_ks3_kernel / lstm_bwd_tile_kernel") if tiled else
                ("lstm_bwd_step2_kernel" if B >= 256 else "lstm_bwd_step_kernel")))
     peak = 2500.0 if bf16 else PEAK_F32_MFMA_TFLOPS       # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
     # traffic: fabric-side bytes per tick / launch from the newest committed rocprofv3 --pmc summary (separate passes,
@@ -815,9 +815,11 @@ def roofline_probe(eng, ws, torch):
                 "not MFMA issue or HBM bytes: see tick_model")
     elif tiled:
         note = ("achieved = isolated BPTT sweep (HIP events on its stream) / launches; the register-tiled step kernels of the "
-                "MFMA-bound regime: every wave owns a (16 MT rows) x (16 NT columns) tile over the whole contraction, operands "
-                "straight from k-chunk-major copies.  `bound` = f32-input MFMA peak; what is left to the peak is the launch seam "
-                "(1.6 us per dependent launch) and the cell epilogue's HBM traffic behind every contraction (DESIGN.md section 5)")
+                "MFMA-bound regime in their three-piece bf16 form (fp32-class accuracy, six bf16 products per f32 product): a "
+                "block owns 64 rows x 64 units, its four waves contract a quarter of K = 4H each into a 64 x 64 register tile, "
+                "operands straight from k-chunk-major bf16 planes, partial tiles through LDS, four adjacent units per lane in the "
+                "cell epilogue.  `bound` = f32-input MFMA peak (the section-8(d) denominator of the ALGORITHMIC f32 FLOP); what is "
+                "left is operand delivery (64 B/clk per CU at the matrix rate), the launch seam and the epilogue (DESIGN.md 6g)")
     else:
         note = ("achieved = isolated BPTT sweep (HIP events on its stream); in_step_* = start-to-start cadence of the "
                 "same launches inside the last timed step (device-side stamps, side-stream GEMMs running beside "
@@ -825,7 +827,7 @@ def roofline_probe(eng, ws, torch):
                 "dependent-chain seam (1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6")
     if bf16:
         note += "  (throughput mode: bf16 operands, so `peak` is the dense bf16 MFMA peak; not the parity path)"
-    return {"bound": "mfma", "limiter": "mfma + launch seam" if tiled else "latency", "kernel": kernel, "achieved": ach,
+    return {"bound": "mfma", "limiter": "operand delivery + launch seam" if tiled else "latency", "kernel": kernel, "achieved": ach,
             "peak": peak,
             "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
             "us_per_launch": us, "launches_per_sweep": launches,

@@ -1413,11 +1413,8 @@ int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* 
     const int tiles = (M / 128) * ceil_div(N, 128);
     static const int target = arcvae_env_int("ARCVAE_PLANE_BLOCKS", 448);     // blocks wanted per launch
     g.z = max(1, min(ceil_div(target, tiles * n), kmax / 16));                // at least 16 K-steps per slice
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24 * 2048);
-        attr = true;
-    }
+    // (> 64 KB of dynamic LDS has to be allowed per kernel; set on every call: idempotent, no host state kept)
+    (void)hipFuncSetAttribute((const void*)wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24 * 2048);
     hipLaunchKernelGGL(wgrad_planes_kernel, dim3(ceil_div(N, 128), M / 128, n * g.z), dim3(512), 3 * 24 * 2048, stream, g);
     return arcvae_launch_status();
 }
