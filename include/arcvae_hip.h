@@ -64,6 +64,11 @@ extern "C" {
                                    * products with ARCVAE_GEMM_SPLIT3 (fp32-class accuracy, less matrix-pipe time beside a sweep) */
 #define ARCVAE_DEC_NO_GPRE 1024   /* arcvae_dec_forward_dense `mode` bit 10: forward only (sampler, loss-only forward) -- `gpre` is not
                                    * written: a layer's GEMM and zero-state cell run as one kernel where the shape allows */
+#define ARCVAE_DEC_PART_HEAD 2048 /* arcvae_dec_forward_dense `mode` / arcvae_dec_backward_dense `flags` bit 11: only the token table and
+                                     layer 0 (forward: tableD, hact[0]; backward: from dh_0 in dh[0 .. B*V*H)) */
+#define ARCVAE_DEC_PART_TAIL 4096 /* bit 12: only fc_out (forward: logits, lse, nxt from hact[L-1]; backward: dWout, dbout and
+                                     dh_top = dlogits . Wout into dh[0 .. B*V*H)); the caller runs layers 1 .. L-1 in between:
+                                     arcvae_dense_stack_forward / _backward */
 #define ARCVAE_DEC_BF16 256       /* arcvae_dec_forward_dense `mode` bit 8 / arcvae_dec_backward_dense `flags` bit 8: the B*V-row
                                    * products with ARCVAE_GEMM_BF16 */
 
@@ -289,6 +294,23 @@ int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const fl
                               float* wcpart, float* dEmb, float* const* dWx, float* const* dbias, float* dWout,
                               float* dbout, int B, int V, int E, int C, int H, int L, int flags /* ARCVAE_DEC_BF16 or 0 */,
                               arcvae_stream_t stream);
+
+/* Layers 1 .. L-1 of the vocabulary-dense decoder -- zero-state cells over R = B*V rows (Q1: hidden = cell = None at every call), an
+ * (L-1)-layer stack at T = 1 -- on the three-piece tile kernels of the encoder's sweeps (lstm_fwd_tile_kernel,
+ * lstm_bwd_tile_ks3_kernel, wgrad_planes_kernel: three bf16 pieces per operand, six products, fp32-class accuracy), for the
+ * MFMA-bound regime where the decoder's exact-f32 GEMMs would run beside the forward sweep.
+ *   arcvae_dense_stack_ok: 1 where that path applies (R % 32 == 0, H % 64 == 0, L >= 2, grids that fill the chip);
+ *   arcvae_dense_stack_ws_floats: *floats = size of `ws` in floats (operand planes of every layer's h, cell states, gate-gradient planes,
+ *   weight planes);  forward: hact [L,R,H] with layer 0 given (arcvae_dec_forward_dense | ARCVAE_DEC_PART_HEAD), layers 1 ..
+ *   written; gates [L-1,R,4H] POST-activation (the gpre workspace holds them in this mode);  backward: dh_top [R,H] in, dG [R,4H]
+ *   scratch, dh0 [R,H] out (the input of arcvae_dec_backward_dense | ARCVAE_DEC_PART_HEAD), dWx[l] / dbias[l] += for l >= 1
+ *   (HOST arrays [L], entry 0 unused), `ws` as the forward left it. */
+int arcvae_dense_stack_ok(long R, int H, int L);
+int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats /* out */);
+int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws, long R,
+                               int H, int L, arcvae_stream_t stream);
+int arcvae_dense_stack_backward(const float* gates, const float* dh_top, float* dG, float* dh0, float* const* dWx,
+                                float* const* dbias, float* ws, long R, int H, int L, arcvae_stream_t stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------------
  * trainer.py:75-76,320,324: MLX optim.Adam, NO bias correction (Q7):

@@ -26,6 +26,8 @@ LSTM_SPLIT3 = 4      # same places: three bf16 pieces per operand, six products 
 PERSIST_BF16 = 2     # arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags: throughput mode (4x4x4 bf16 blocks)
 DEC_BF16 = 256       # arcvae_dec_forward_dense mode bit / arcvae_dec_backward_dense flags bit
 DEC_SPLIT3 = 512     # same places: three-piece (fp32-class) products
+DEC_PART_HEAD = 2048  # arcvae_dec_forward_dense mode / _backward_dense flags bit: token table + layer 0 only
+DEC_PART_TAIL = 4096  # ... fc_out only (layers 1 .. L-1 by arcvae_dense_stack_forward / _backward)
 DEC_NO_GPRE = 1024   # arcvae_dec_forward_dense mode bit: forward only, pre-activations not kept (fused GEMM + cell)
 WGRAD_BF16 = 128     # arcvae_enc_lstm_wgrad parts bit
 
@@ -46,6 +48,10 @@ SIGNATURES = {
     "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_lstm_tiled": [_i, _i, _i],
     "arcvae_enc_lstm_operand_slots": [_i, _i, _i, _i, _i],
+    "arcvae_dense_stack_ok": [_l, _i, _i],
+    "arcvae_dense_stack_ws_floats": [_l, _i, _i, _lp],
+    "arcvae_dense_stack_forward": [_pp, _pp, _vp, _vp, _vp, _l, _i, _i, _vp],
+    "arcvae_dense_stack_backward": [_vp, _vp, _vp, _vp, _pp, _pp, _vp, _l, _i, _i, _vp],
     "arcvae_enc_lstm_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_prologue": [_vp, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

@@ -263,10 +263,23 @@ def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: in
         mode |= _lib.DEC_NO_GPRE
     wx, _k1 = _layer_ptrs(dec, d.L, "Wx")
     bs, _k2 = _layer_ptrs(dec, d.L, "bias")
-    call("arcvae_dec_forward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
-         ptr(dec.p("fc_out.bias")), ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.logits),
-         ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode | _dec_gemm_bits(ws),
-         float(temperature), stream_ptr())
+
+    def part(bits):
+        call("arcvae_dec_forward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
+             ptr(dec.p("fc_out.bias")), ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.logits),
+             ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode | bits | _dec_gemm_bits(ws),
+             float(temperature), stream_ptr())
+
+    if keep_gpre and getattr(ws, "dense_ws", None) is not None:
+        # MFMA-bound regime (StepEngine.workspace): layers 1 .. L-1 -- zero-state cells over B*V rows -- on the three-piece tile
+        # kernels of the encoder's sweeps; `gpre` then holds the POST-activation gates (what their backward reads)
+        part(_lib.DEC_PART_HEAD)
+        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), ptr(ws.gpre), ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, stream_ptr())
+        part(_lib.DEC_PART_TAIL)
+        ws.dense_fwd = True
+        return
+    ws.dense_fwd = False
+    part(0)
 
 
 def decoder_chain(ws: Workspace, d: ModelDims) -> None:
@@ -283,10 +296,22 @@ def decoder_backward(dec: ParamStore, ws: Workspace, d: ModelDims, inv_count: fl
     bs, _k2 = _layer_ptrs(dec, d.L, "bias")
     dwx, _k3 = _layer_ptrs(dec, d.L, "Wx", grad=True)
     dbs, _k4 = _layer_ptrs(dec, d.L, "bias", grad=True)
-    call("arcvae_dec_backward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
-         ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.dlogits), ptr(ws.ddh), ptr(ws.ddG),
-         ptr(ws.dtableD), ptr(ws.wcpart), ptr(dec.g("embedding.weight")), dwx, dbs, ptr(dec.g("fc_out.weight")),
-         ptr(dec.g("fc_out.bias")), ws.B, d.V, d.E, d.C, d.H, d.L, _dec_gemm_bits(ws), s)
+
+    def part(bits, dh):
+        call("arcvae_dec_backward_dense", ptr(dec.p("embedding.weight")), wx, bs, ptr(dec.p("fc_out.weight")),
+             ptr(ws.cond), ptr(ws.tableD), ptr(ws.hact), ptr(ws.gpre), ptr(ws.dlogits), dh, ptr(ws.ddG),
+             ptr(ws.dtableD), ptr(ws.wcpart), ptr(dec.g("embedding.weight")), dwx, dbs, ptr(dec.g("fc_out.weight")),
+             ptr(dec.g("fc_out.bias")), ws.B, d.V, d.E, d.C, d.H, d.L, bits | _dec_gemm_bits(ws), s)
+
+    if getattr(ws, "dense_fwd", False):
+        # the forward of this step ran layers 1 .. L-1 on the tile kernels (decoder_forward_dense): fc_out's part, the stack's
+        # backward on the same kernels (dh_top in ddh[0] -> dh_0 in ddh[1]), then layer 0 and the token table
+        part(_lib.DEC_PART_TAIL, ptr(ws.ddh))
+        call("arcvae_dense_stack_backward", ptr(ws.gpre), ptr(ws.ddh[0]), ptr(ws.ddG), ptr(ws.ddh[1]), dwx, dbs,
+             ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, s)
+        part(_lib.DEC_PART_HEAD, ptr(ws.ddh[1]))
+        return
+    part(0, ptr(ws.ddh))
 
 
 def latent_loss(ws: Workspace, d: ModelDims, free_bits: float, with_grads: bool) -> None:
@@ -880,6 +905,12 @@ class StepEngine:
                 ws.hseq_t = torch.empty(self.d.L, slots, B * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
                 if train:
                     ws.dG_t = torch.empty(self.d.L, slots, B * 4 * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
+            # ... and the dense decoder's layers 1 .. L-1 (zero-state cells over B*V rows) on the same kernels
+            ws.dense_ws = None
+            if train and not ws.bf16 and lib.arcvae_dense_stack_ok(B * self.d.V, self.d.H, self.d.L) == 1:
+                n = C.c_long(0)
+                lib.arcvae_dense_stack_ws_floats(B * self.d.V, self.d.H, self.d.L, C.byref(n))
+                ws.dense_ws = torch.empty(n.value, dtype=torch.float32, device=self.device)
             ws.planes = bool(train and slots == T and _lstm_flags(ws) == _lib.LSTM_SPLIT3 and B % 32 == 0
                              and lib.arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3
                              and os.environ.get("ARCVAE_WGRAD_PLANES", "1") != "0"

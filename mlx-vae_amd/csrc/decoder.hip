@@ -363,17 +363,24 @@ extern "C" int arcvae_dec_forward_dense(const float* emb, const float* const* Wx
     // the B*V-row products: throughput mode = bf16 operands; ARCVAE_DEC_SPLIT3 = three bf16 pieces, six products (fp32-class)
     const int BF = (mode & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : ((mode & ARCVAE_DEC_SPLIT3) ? ARCVAE_GEMM_SPLIT3 : 0);
     const bool no_gpre = (mode & ARCVAE_DEC_NO_GPRE) != 0 && BF == 0;   // forward only: fuse GEMM + cell (exact-f32 path)
-    mode &= ~(ARCVAE_DEC_BF16 | ARCVAE_DEC_SPLIT3 | ARCVAE_DEC_NO_GPRE);
+    // ARCVAE_DEC_PART_HEAD: only the token table and layer 0; ARCVAE_DEC_PART_TAIL: only the logits and the row statistics -- the
+    // caller runs layers 1 .. L-1 in between (arcvae_dense_stack_forward: the three-piece tile kernels)
+    const bool head_only = (mode & ARCVAE_DEC_PART_HEAD) != 0, tail_only = (mode & ARCVAE_DEC_PART_TAIL) != 0;
+    mode &= ~(ARCVAE_DEC_BF16 | ARCVAE_DEC_SPLIT3 | ARCVAE_DEC_NO_GPRE | ARCVAE_DEC_PART_HEAD | ARCVAE_DEC_PART_TAIL);
     if (mode == 1 && !(temperature > 0.f)) return ARCVAE_ERR_ARG;
     for (int l = 0; l < L; ++l)
         if (!Wx[l] || !bias[l]) return ARCVAE_ERR_ARG;
     const int G = 4 * H;
     const long R = (long)B * V;
-    int rc = arcvae_gemm_f32(0, 1, V, G, E, emb, E, Wx[0], E + C, tableD, G, nullptr, 0, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(dec_l0_fwd_kernel, dim3(ceil_div(H, 64), V, ceil_div(B, 64)), dim3(256), 0, stream, tableD, cond, Wx[0],
-                       bias[0], hact, B, V, E, C, H);
-    for (int l = 1; l < L; ++l) {
+    int rc = ARCVAE_OK;
+    if (!tail_only) {
+        rc = arcvae_gemm_f32(0, 1, V, G, E, emb, E, Wx[0], E + C, tableD, G, nullptr, 0, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dec_l0_fwd_kernel, dim3(ceil_div(H, 64), V, ceil_div(B, 64)), dim3(256), 0, stream, tableD, cond, Wx[0],
+                           bias[0], hact, B, V, E, C, H);
+        if (head_only) return arcvae_launch_status();
+    }
+    for (int l = 1; l < L && !tail_only; ++l) {
         float* Gl = gpre + (long)(l - 1) * R * G;
         if (no_gpre && R >= 4096 &&
             arcvae_gemm_cell_zero((int)R, H, H, hact + (long)(l - 1) * R * H, H, Wx[l], H, bias[l], hact + (long)l * R * H,
@@ -459,16 +466,24 @@ extern "C" int arcvae_dec_backward_dense(const float* emb, const float* const* W
     const int Ri = (int)R;
     const int BF = (flags & ARCVAE_DEC_BF16) ? ARCVAE_GEMM_BF16 : ((flags & ARCVAE_DEC_SPLIT3) ? ARCVAE_GEMM_SPLIT3 : 0);
     const int SK = ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | (BF & ARCVAE_GEMM_BF16);   // (TN "+=": the split TN kernel either way)
+    // ARCVAE_DEC_PART_TAIL: only fc_out's gradients and dh_top = dlogits . Wout (into dh[0 .. R*H)); ARCVAE_DEC_PART_HEAD: only
+    // layer 0 and the token table, from dh_0 in dh[0 .. R*H) -- the caller runs layers L-1 .. 1 in between
+    // (arcvae_dense_stack_backward)
+    const bool head_only = (flags & ARCVAE_DEC_PART_HEAD) != 0, tail_only = (flags & ARCVAE_DEC_PART_TAIL) != 0;
     float* dhA = dh;
     float* dhB = dh + R * H;
     const float* hTop = hact + (long)(L - 1) * R * H;
-    int rc = arcvae_gemm_f32(1, 0, V, H, Ri, dlogits, V, hTop, H, dWout, H, nullptr, SK, stream);  // dWout += dL^T h
-    if (rc) return rc;
-    rc = arcvae_colsum_accum(dlogits, Ri, V, V, dbout, 1.0f, stream);
-    if (rc) return rc;
-    rc = arcvae_gemm_f32(0, 0, Ri, H, V, dlogits, V, Wout, H, dhA, H, nullptr, BF, stream);  // dh = dL Wout
-    if (rc) return rc;
-    for (int l = L - 1; l >= 1; --l) {
+    int rc = ARCVAE_OK;
+    if (!head_only) {
+        rc = arcvae_gemm_f32(1, 0, V, H, Ri, dlogits, V, hTop, H, dWout, H, nullptr, SK, stream);  // dWout += dL^T h
+        if (rc) return rc;
+        rc = arcvae_colsum_accum(dlogits, Ri, V, V, dbout, 1.0f, stream);
+        if (rc) return rc;
+        rc = arcvae_gemm_f32(0, 0, Ri, H, V, dlogits, V, Wout, H, dhA, H, nullptr, BF, stream);  // dh = dL Wout
+        if (rc) return rc;
+        if (tail_only) return arcvae_launch_status();
+    }
+    for (int l = L - 1; l >= 1 && !head_only; --l) {
         const float* Gl = gpre + (long)(l - 1) * R * G;
         hipLaunchKernelGGL(cell_zero_bwd_kernel, dim3(blocks_for(R * H)), dim3(256), 0, stream, Gl, dhA, dG, R, H);
         rc = arcvae_gemm_f32(1, 0, G, H, Ri, dG, G, hact + (long)(l - 1) * R * H, H, dWx[l], H, nullptr, SK, stream);

@@ -3234,6 +3234,159 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
     return arcvae_launch_status();
 }
 
+// ---- the dense decoder's layers l >= 1 on the three-piece tile kernels (round 3) ---------------------------------------------
+// models/decoder.py:134-188 with the reference's quirk (Q1/Q2): the decoder's recurrence is dead, every layer l >= 1 is a
+// ZERO-STATE cell over R = B*V rows -- h_l = o . tanh(i . g) of W_l h_{l-1} + b_l -- i.e. an L-1 layer stack at T = 1, which is
+// exactly what lstm_fwd_tile_kernel (cprev = null), lstm_bwd_tile_ks3_kernel (cprev = dcin = null) and wgrad_planes_kernel
+// compute.  In the MFMA-bound regime (configs[2]: R = 40960 rows) the decoder's exact-f32 GEMMs were 11 ms of kernel time per
+// step beside the forward sweep; here they run as three bf16 pieces per operand with fp32-class accuracy, every activation
+// split once by the epilogue that produces it.  Workspace (floats), in this order:
+//   hact_t [L][R*H*3/2] operand planes of every layer's h;  cseq [L-1][R*H];  dG_t [2][R*4H*3/2];  dc [R*H];
+//   wt [L-1][4H*H*3/2] forward weight planes;  wT [L-1][H*4H*3/2] transposed weight planes
+namespace {
+__global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ X, __bf16* __restrict__ P, long R, int H) {
+    // X [R, H] f32 -> [plane][H >> 5][R][32] bf16 (hi, mid, lo); a thread: four adjacent units of a row
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int hq = H >> 2;
+    if (i >= R * hq) return;
+    const long row = i / hq;
+    const int unit = 4 * (int)(i - row * hq);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(X + row * H + unit);
+    typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+    __bf16 pc[3][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) split3_bf16(v[k], pc[0][k], pc[1][k], pc[2][k]);
+    __bf16* tp = P + ((long)(unit >> 5) * R + row) * 32 + (unit & 31);
+#pragma unroll
+    for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<bf16x4_l*>(tp + pz * R * H) = bf16x4_l{pc[pz][0], pc[pz][1], pc[pz][2], pc[pz][3]};
+}
+struct DenseWs {
+    float *hact_t, *cseq, *dG_t, *dc, *wt, *wT;
+    long sHt, sGt, wsz, total;
+};
+inline DenseWs dense_ws(float* base, long R, int H, int L) {
+    DenseWs w;
+    const long G = 4L * H;
+    w.sHt = R * H * 3 / 2; w.sGt = R * G * 3 / 2; w.wsz = G * H * 3 / 2;
+    long o = 0;
+    w.hact_t = base + o; o += (long)L * w.sHt;
+    w.cseq = base + o; o += (long)(L - 1) * R * H;
+    w.dG_t = base + o; o += 2 * w.sGt;
+    w.dc = base + o; o += R * H;
+    w.wt = base + o; o += (long)(L - 1) * w.wsz;
+    w.wT = base + o; o += (long)(L - 1) * w.wsz;
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+// 1: layers 1 .. L-1 of a dense stack over R rows run on the tile kernels (grids that fill the chip, whole 32-row K-steps);
+// ARCVAE_DENSE_TILED: 1 auto (default), 0 never, 2 whenever the shape allows (tests).
+extern "C" int arcvae_dense_stack_ok(long R, int H, int L) {
+    const int mode = arcvae_env_int("ARCVAE_DENSE_TILED", 1);
+    if (mode == 0 || L < 2 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || R <= 0 || R > 0x3fffffff || (R % 32) != 0) return 0;
+    if (mode == 2) return 1;
+    return (R / 64) * (H / 64) >= 512 ? 1 : 0;
+}
+extern "C" int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats) {
+    if (R <= 0 || H <= 0 || L < 2 || !floats) return ARCVAE_ERR_ARG;
+    *floats = dense_ws(nullptr, R, H, L).total;
+    return ARCVAE_OK;
+}
+
+// hact [L, R, H]: layer 0 given (dec_l0_fwd_kernel), layers 1 .. L-1 written;  gates [L-1, R, 4H] POST-activation i, f, g, o of
+// layers 1 .. (what the backward below reads -- not the pre-activations arcvae_dec_forward_dense keeps);  Wx / bias: HOST arrays
+// [L] of device pointers (entry 0 unused).
+extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws,
+                                          long R, int H, int L, hipStream_t stream) {
+    if (!Wx || !bias || !hact || !gates || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
+    const int G = 4 * H, Ri = (int)R;
+    const DenseWs w = dense_ws(ws, R, H, L);
+    {   // weight planes, both layouts (arcvae_tile_weights modes 4 / 5)
+        const float* src[2 * ARCVAE_MAX_LAYERS];
+        float* dst[2 * ARCVAE_MAX_LAYERS];
+        int cols[2 * ARCVAE_MAX_LAYERS], mode[2 * ARCVAE_MAX_LAYERS];
+        int n = 0;
+        for (int l = 1; l < L; ++l) {
+            if (!Wx[l] || !bias[l]) return ARCVAE_ERR_ARG;
+            src[n] = Wx[l]; dst[n] = w.wt + (l - 1) * w.wsz; cols[n] = H; mode[n] = 4; ++n;
+            src[n] = Wx[l]; dst[n] = w.wT + (l - 1) * w.wsz; cols[n] = H; mode[n] = 5; ++n;
+        }
+        const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
+        if (rc != ARCVAE_OK) return rc;
+    }
+    hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)((R * (H >> 2) + 255) / 256)), dim3(256), 0, stream, hact,
+                       reinterpret_cast<__bf16*>(w.hact_t), R, H);
+    for (int l = 1; l < L; ++l) {
+        FwdArgs a;
+        a.B = Ri; a.H = H; a.V = 1; a.prio = 0; a.remap = 0; a.trace = nullptr; a.dbg = 0;
+        FwdJob& j = a.job[0];
+        j.xin = w.hact_t + (long)(l - 1) * w.sHt; j.Wx = w.wt + (l - 1) * w.wsz;
+        j.hprev = nullptr; j.Wh = nullptr;
+        j.pre = bias[l]; j.tok = nullptr; j.cprev = nullptr;
+        j.h = hact + (long)l * R * H;
+        j.ht = w.hact_t + (long)l * w.sHt;
+        j.c = w.cseq + (long)(l - 1) * R * H;
+        j.gates = gates + (long)(l - 1) * R * G;
+        j.oct = nullptr;
+        for (int k = 1; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
+        launch_fwd_tile<4, 4, 2>(a, Ri, H, 1, stream);
+    }
+    return arcvae_launch_status();
+}
+
+// Backward of the above from dh_top [R, H] (gradient of the top layer's h): dWx_l += dG_l^T h_{l-1}, dbias_l += colsum(dG_l)
+// for l = L-1 .. 1 and dh0 [R, H] = dG_1 . Wx_1 (the input of dec_l0_bwd_kernel).  dG [R, 4H]: scratch (every layer's gate
+// gradients pass through it).  `ws` as the forward left it.
+extern "C" int arcvae_dense_stack_backward(const float* gates, const float* dh_top, float* dG, float* dh0, float* const* dWx,
+                                           float* const* dbias, float* ws, long R, int H, int L, hipStream_t stream) {
+    if (!gates || !dh_top || !dG || !dh0 || !dWx || !dbias || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(dh_top) % 16) != 0) return ARCVAE_ERR_ARG;
+    const int G = 4 * H, Ri = (int)R;
+    const DenseWs w = dense_ws(ws, R, H, L);
+    auto launch = [&](BwdArgs& a) {
+        for (int k = 1; k < ARCVAE_MAX_BWD_JOBS; ++k) a.job[k] = a.job[0];
+        hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 64 * 1024, stream, a);
+    };
+    for (int l = L - 1; l >= 1; --l) {
+        if (!dWx[l] || !dbias[l]) return ARCVAE_ERR_ARG;
+        BwdArgs a;
+        a.B = Ri; a.H = H; a.prio = 0; a.remap = 0; a.trace = nullptr; a.dbg = 0; a.signal = nullptr;
+        BwdJob& j = a.job[0];
+        j.kind = 0;
+        const bool top = l == L - 1;
+        j.src = top ? nullptr : w.dG_t + ((l + 1) & 1) * w.sGt;          // dh_l = dG_{l+1} . Wx_{l+1}
+        j.WT = top ? nullptr : w.wT + (long)l * w.wsz;                    // (slot l = layer l + 1)
+        j.ext = top ? dh_top : nullptr; j.ext_ld = H;
+        j.gates = gates + (long)(l - 1) * R * G;
+        j.c = w.cseq + (long)(l - 1) * R * H;
+        j.cprev = nullptr; j.dcin = nullptr; j.dcout = w.dc;
+        j.out = dG; j.outt = w.dG_t + (l & 1) * w.sGt; j.oct = nullptr;
+        launch(a);
+        // dWx_l += dG_l^T . h_{l-1} from the planes (one time slot of R rows), dbias_l += colsum(dG_l)
+        const void* Ap = w.dG_t + (l & 1) * w.sGt;
+        const void* Bp = w.hact_t + (long)(l - 1) * w.sHt;
+        const int zero = 0, one = 1;
+        float* Cp = dWx[l];
+        int rc = arcvae_wgrad_planes_group(1, G, H, Ri, &Ap, &zero, &Bp, &zero, &one, &Cp, H, stream);
+        if (rc) return rc;
+        rc = arcvae_colsum_accum(dG, Ri, G, G, dbias[l], 1.0f, stream);
+        if (rc) return rc;
+    }
+    {   // dh0 = dG_1 . Wx_1
+        BwdArgs a;
+        a.B = Ri; a.H = H; a.prio = 0; a.remap = 0; a.trace = nullptr; a.dbg = 0; a.signal = nullptr;
+        BwdJob& j = a.job[0];
+        j.kind = 1;
+        j.src = w.dG_t + (1 & 1) * w.sGt; j.WT = w.wT;
+        j.ext = nullptr; j.ext_ld = H;
+        j.gates = nullptr; j.c = nullptr; j.cprev = nullptr; j.dcin = nullptr; j.dcout = nullptr;
+        j.out = dh0; j.outt = nullptr; j.oct = nullptr;
+        launch(a);
+    }
+    return arcvae_launch_status();
+}
+
 // Weight gradients of the stack from dG over the time range [t_lo, t_hi) (all "+=" into the caller's
 // gradient buffers), so that chunks can run on another stream while the BPTT sweep is still going:
 //   l >= 1: dWx_l += dG_l[t]^T . hseq_{l-1}[t];  all l: dWh_l += dG_l[t]^T . hseq_l[t-1] (t >= 1);  dbias_l += colsum

@@ -40,6 +40,8 @@ int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* 
 int arcvae_gemm_cell_zero(int M, int H, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                           float* Hout, hipStream_t stream);
 #define ARCVAE_DEC_NO_GPRE 1024    /* arcvae_dec_forward_dense `mode` bit 10: forward only, the layers' pre-activations are not kept */
+#define ARCVAE_DEC_PART_HEAD 2048  /* arcvae_dec_forward_dense `mode` / _backward_dense `flags` bit 11: only the token table and layer 0 */
+#define ARCVAE_DEC_PART_TAIL 4096  /* bit 12: only fc_out (logits + row statistics / its gradients + dh_top): layers 1 .. L-1 by the caller */
 
 // internal (C++ linkage): two skinny products in one launch, see gemm.hip
 int arcvae_gemm_skinny_pair(int transB, const int* M, const int* N, const int* K, const float* const* A, const int* lda,

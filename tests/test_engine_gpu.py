@@ -333,6 +333,38 @@ def test_operand_plane_weight_gradients(H, L, B, T, C, ks3, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("H,L,B,T,C", [(64, 2, 32, 6, 1), (192, 3, 40, 5, 2), (256, 4, 16, 4, 1), (128, 2, 72, 4, 1)])
+def test_dense_decoder_layers_on_tile_kernels(H, L, B, T, C, monkeypatch):
+    """MFMA-bound regime: the dense decoder's layers 1 .. L-1 (zero-state cells over B*V rows, Q1) run on the encoder sweeps'
+    three-piece tile kernels -- arcvae_dense_stack_forward / _backward between the HEAD and TAIL parts of
+    arcvae_dec_forward_dense / _backward_dense -- forced on at small shapes (ARCVAE_DENSE_TILED=2): ragged 64-row blocks, H not a
+    multiple of 128, two to four layers, one and two conditions.  Everything against the fp64 oracle at 1e-4, both metrics."""
+    monkeypatch.setenv("ARCVAE_DENSE_TILED", "2")
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    ws = eng.workspace(B, T, True)
+    assert ws.dense_ws is not None and ws.dense_fwd
+    for k in ("total_loss", "recon_loss", "kl_loss", "mutual_info"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+        else:
+            assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)
+    assert not bad, bad
+
+
 def test_three_piece_sweeps_have_f32_accuracy(monkeypatch):
     """The three-piece form of the tiled sweeps is a PARITY path: its error against the fp64 oracle must be of the exact-f32
     kernels' size, not bf16's -- hidden states and the recurrent weight gradient over a 24-step sweep at H 256 / L 2."""
