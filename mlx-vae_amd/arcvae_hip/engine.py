@@ -906,8 +906,13 @@ class StepEngine:
                 if train:
                     ws.dG_t = torch.empty(self.d.L, slots, B * 4 * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
             # ... and the dense decoder's layers 1 .. L-1 (zero-state cells over B*V rows) on the same kernels
+            # (only where the encoder's sweeps are launch-based tile kernels themselves: beside a PERSISTENT sweep the tile kernels'
+            # blocks -- 370-420 registers, 64-70 KB of LDS -- cannot be resident and the two serialise: bs 128 1.63 -> 2.00 ms)
             ws.dense_ws = None
-            if train and not ws.bf16 and lib.arcvae_dense_stack_ok(B * self.d.V, self.d.H, self.d.L) == 1:
+            dense_force = os.environ.get("ARCVAE_DENSE_TILED", "1") == "2"
+            if (train and not ws.bf16 and lib.arcvae_dense_stack_ok(B * self.d.V, self.d.H, self.d.L) == 1
+                    and (dense_force or (lib.arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3
+                                         and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)))):
                 n = C.c_long(0)
                 lib.arcvae_dense_stack_ws_floats(B * self.d.V, self.d.H, self.d.L, C.byref(n))
                 ws.dense_ws = torch.empty(n.value, dtype=torch.float32, device=self.device)
