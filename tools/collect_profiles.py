@@ -29,3 +29,7 @@ cp(first(f"{G}/prof_{tag}_big/*/*_kernel_stats.csv"), f"{rnd}_big_fp32_kernel_st
 cp(first(f"{G}/prof_{tag}_sampler/*/*_kernel_stats.csv"), f"{rnd}_sampler_kernel_stats.csv")
 cp(first(f"{G}/prof_{tag}_shard/*/*_kernel_stats.csv"), f"{rnd}_shard256_kernel_stats.csv")
 cp(f"{G}/tick_stamps_{tag}.txt", f"{rnd}_tick_stamps.txt")
+cp(first(f"{G}/prof_{tag}_strong/*/*_kernel_stats.csv"), f"{rnd}_strong2048_kernel_stats.csv")
+cp(f"{G}/planes_{tag}.txt", f"{rnd}_planes_gemm.txt")
+cp(f"{G}/trace_big_{tag}.txt", f"{rnd}_step_trace_configs2.txt")
+cp(f"{G}/phase_big_{tag}.txt", f"{rnd}_phase_times_configs2.txt")
