@@ -541,6 +541,16 @@ class EncoderBackwardPlan:
             # throughput mode: one bf16 product per GEMM step.  Not beside a persistent sweep: there the matrix pipe is
             # idle anyway and what counts is what fits on the sweep's SIMDs (measured at bs 64: 1.077 vs 1.03 ms)
             parts |= _lib.WGRAD_BF16
+        elif getattr(ws, "pl_g", None) is not None and not self.persistent:
+            # 256..512 rows per GPU (per-step-launch BPTT, f32 operand copies): the call splits dG / h of its time range into
+            # three-piece planes itself (one elementwise pass) and runs the plane GEMMs -- 2.7x less matrix-pipe time than the
+            # exact-f32 tile GEMM beside the sweep, no re-splitting per tile
+            parts |= 2048 | 4096 | 16
+            call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
+                 ptr(ws.hseq), ptr(ws.dG), ptr(table if table is not None else ws.dtable0), ptr(ws.onehot),
+                 ptr(enc.g("embedding.weight")), self._dwx[0], self._dwh[0], self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L,
+                 t_lo, t_hi, int(first), int(last), parts, ptr(ws.pl_h), ptr(ws.pl_g), stream_ptr())
+            return
         elif getattr(ws, "planes", False) and not self.persistent:
             # MFMA-bound regime, three-piece sweeps: the GEMMs read the sweeps' operand planes (all T slots kept) -- see
             # StepEngine.workspace; (| 16: the token-table one-hot GEMM keeps its exact-f32 tile form)
@@ -921,6 +931,18 @@ class StepEngine:
                              and os.environ.get("ARCVAE_WGRAD_PLANES", "1") != "0"
                              and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)
                              and lib.arcvae_enc_lstm_bwd_persistent_ok(B, T, self.d.H, self.d.L) != 1)
+            # Mid-size batches (the BPTT on per-step launches, not tiled), opt-in (ARCVAE_WGRAD_CONVERT=1; 2: any batch, tests):
+            # scratch plane rings for the weight-gradient calls, which then split dG / h themselves and run the plane GEMMs
+            # (arcvae_enc_lstm_wgrad parts bits 11 | 12).  Parity-green, measured SLOWER than the exact-f32 tile GEMMs there:
+            # bs 256 3.28 vs 3.04 ms, bs 512 6.46 vs 6.12 -- the plane GEMM's blocks (144 KB of LDS, two waves per SIMD) and
+            # the split pass take more from the sweep beside them than the matrix time they save.
+            ws.pl_h = ws.pl_g = None
+            conv = os.environ.get("ARCVAE_WGRAD_CONVERT", "0")
+            if (train and not ws.planes and not ws.bf16 and B % 32 == 0 and self.d.H % 64 == 0 and conv != "0"
+                    and (conv == "2" or B >= 256) and not (lib.arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) & 2)
+                    and not bptt_reduce_scatter_ok(ws, self.d)):
+                ws.pl_h = torch.empty(self.d.L * T * B * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
+                ws.pl_g = torch.empty(self.d.L * T * B * 4 * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
             self._ws[key] = ws
             self._probe_persistent(ws)
         return self._ws[key]

@@ -3245,7 +3245,9 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
 //   wt [L-1][4H*H*3/2] forward weight planes;  wT [L-1][H*4H*3/2] transposed weight planes
 namespace {
 __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ X, __bf16* __restrict__ P, long R, int H) {
-    // X [R, H] f32 -> [plane][H >> 5][R][32] bf16 (hi, mid, lo); a thread: four adjacent units of a row
+    // X [slots][R, H] f32 -> [slots][plane][H >> 5][R][32] bf16 (hi, mid, lo); a thread: four adjacent units of a row; blockIdx.y = slot
+    X += (long)blockIdx.y * R * H;
+    P += (long)blockIdx.y * 3 * R * H;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int hq = H >> 2;
     if (i >= R * hq) return;
@@ -3399,6 +3401,7 @@ extern "C" int arcvae_dense_stack_backward(const float* gates, const float* dh_t
 //   bit 4 = exact-f32 MFMA tile GEMMs instead of the split-bf16 kernel (45 instead of 208 registers per lane: what
 //   fits on a SIMD beside a persistent sweep wave of more than 296 registers, i.e. the 2 / 4 row-group sweeps)
 //   bit 11 = h_oct / dG_oct are the three-plane operand rings hseq_t / dG_t with all T slots: GEMMs from the planes
+//   bit 12 (with 11) = those rings are scratch: this call first splits dG / h of its time range into them (mid-size batches)
 //   onehot_ws [T*B, roundup(V,4)] workspace: one-hot token rows, written when `first` != 0 (token-table part)
 extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx0,
                                      const float* hseq, const float* dG, float* dtable_ws, float* onehot_ws,
@@ -3443,6 +3446,26 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                 if (do_wx && l > 0) {
                     Ag[n] = dGl + (long)t_lo * B * G; Bg[n] = hseq + (l - 1) * lH + (long)t_lo * B * H;
                     Cg[n] = dWx[l]; Sg[n] = dbias[l]; Kg[n] = nt * B; ++n;   // same rows as the bias sum: colsum(dG_l[t_lo..t_hi))
+                }
+            }
+            if ((parts & 4096) && (parts & 2048) && h_oct && dG_oct) {
+                // bit 12 (with bit 11): the plane rings are the CALLER's scratch -- the sweeps of this shape do not write planes (the
+                // persistent / per-step-launch kernels of 256..512 rows): split dG[t_lo, t_hi) and the h slots they pair with
+                // here, one elementwise pass (10 bytes per value), then the GEMMs from the planes as below
+                if ((B % 32) != 0 || (H % 64) != 0) return ARCVAE_ERR_ARG;
+                __bf16* hp = static_cast<__bf16*>(const_cast<void*>(h_oct));
+                __bf16* gp = static_cast<__bf16*>(const_cast<void*>(dG_oct));
+                const int h_lo = t_lo > 0 ? t_lo - 1 : 0;                         // dWh pairs dG[t] with h[t-1]
+                // (a call that forms only the dWx_l or only the dWh_l splits what IT reads; where two calls on two streams split the
+                // same slab they write the same bytes)
+                for (int l = 0; l < L; ++l) {
+                    if (do_wh || l > 0)
+                        hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)(((long)B * (G >> 2) + 255) / 256), nt), dim3(256), 0, stream,
+                                           dG + l * lG + (long)t_lo * B * G, gp + 3 * (l * lG + (long)t_lo * B * G), (long)B, G);
+                    const int a0 = do_wh ? h_lo : t_lo, a1 = (do_wx && l < L - 1) ? t_hi : t_hi - 1;   // slots of h_l this call reads
+                    if (a1 > a0 && (do_wh || l < L - 1))
+                        hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)(((long)B * (H >> 2) + 255) / 256), a1 - a0), dim3(256), 0, stream,
+                                           hseq + l * lH + (long)a0 * B * H, hp + 3 * (l * lH + (long)a0 * B * H), (long)B, H);
                 }
             }
             if ((parts & 2048) && h_oct && dG_oct) {

@@ -365,6 +365,34 @@ def test_dense_decoder_layers_on_tile_kernels(H, L, B, T, C, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("H,L,B,T,C", [(192, 3, 64, 6, 2), (64, 2, 32, 5, 1), (320, 1, 96, 4, 1), (256, 2, 288, 6, 1)])
+def test_weight_gradients_from_planes_split_on_the_fly(H, L, B, T, C, monkeypatch):
+    """Mid-size batches (per-step-launch BPTT with f32 operand copies): arcvae_enc_lstm_wgrad parts bits 11 | 12 -- the call splits
+    dG / h of its time range into three-piece planes (planes_from_f32_kernel) and runs the plane GEMMs; forced on at small shapes
+    (ARCVAE_WGRAD_CONVERT=2), including the 288-row case where the dWx and dWh parts run on two streams and a single-layer stack."""
+    monkeypatch.setenv("ARCVAE_WGRAD_CONVERT", "2")
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=16, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(2):
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    assert eng.workspace(B, T, True).pl_g is not None
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+        else:
+            assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)
+    assert not bad, bad
+
+
 def test_three_piece_sweeps_have_f32_accuracy(monkeypatch):
     """The three-piece form of the tiled sweeps is a PARITY path: its error against the fp64 oracle must be of the exact-f32
     kernels' size, not bf16's -- hidden states and the recurrent weight gradient over a 24-step sweep at H 256 / L 2."""
