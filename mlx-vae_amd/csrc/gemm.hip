@@ -1228,6 +1228,7 @@ struct PlaneTN {
     const __bf16* A;    // dG planes of the layer, slot of t = 0: [t][plane][M >> 5][rows][32]
     const __bf16* B;    // h planes of the source layer:            [t][plane][N >> 5][rows][32]
     float* C;           // [M, N] row-major, +=
+    float* colsum;      // optional [M]: += sum over rows of dG (the bias gradient rides as a product with a column of ones)
     int tA0, tB0;       // first time slot of each operand
     int ksteps;         // (time steps) * (rows / 32)
 };
@@ -1273,6 +1274,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
         p.A = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.A)));
         p.B = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.B)));
         p.C = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.C)));
+        p.colsum = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.colsum)));
         p.tA0 = __builtin_amdgcn_readfirstlane(q.tA0); p.tB0 = __builtin_amdgcn_readfirstlane(q.tB0);
         p.ksteps = __builtin_amdgcn_readfirstlane(q.ksteps);
     }
@@ -1333,6 +1335,16 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias rider: colsum[m] += sum_k dG[k][m] as one more product per A fragment with a B operand of ones (every column of the
+    // result is the sum; column 0 is kept) -- by the waves of the block column n0 = 0 that own the tile's first 64 columns.
+    // Replaces a separate pass over the f32 dG (1.4 ms of kernel time per configs[2] step).
+    const bool rider = !loader && p.colsum != nullptr && n0 == 0 && wn == 0;     // wave-uniform
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (__bf16)1.0f;
     // Three LDS stages, two K-steps in flight: a stage is read one barrier AFTER the counted wait that retires its LDS-DMA (each
     // wave waits for its own 12, the barrier makes that true for all four), and re-filled one barrier after its last read.
     if (loader) {
@@ -1355,6 +1367,13 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) fa[pl][tt] = frag(cur, 0, pl, tt);
+            if (rider) {
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)       // lo, mid, hi: small pieces first
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pl][i], ones, accb[i], 0, 0, 0);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bf16x8_t fb[3];
@@ -1376,6 +1395,12 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
         cur = cur == 2 ? 0 : cur + 1;
     }
     if (loader || !active) return;
+    if (rider && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + r, accb[i][r]);
+    }
     // D[m = 4 (lane >> 4) + r][n = lane & 15] of tile (i, j)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1396,7 +1421,8 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
 // dW_i[M, N] += dG_i^T . h_i over the time steps [t, t + nT) of each problem, operands = the sweeps' three-plane copies (all
 // time slots kept).  M % 128 == 0, N % 64 == 0, rows % 32 == 0.  Internal (ops.h).
 int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* A, const int* tA0, const void* const* B,
-                              const int* tB0, const int* nT, float* const* C, int ldc, hipStream_t stream) {
+                              const int* tB0, const int* nT, float* const* C, int ldc, float* const* colsum /* optional */,
+                              hipStream_t stream) {
     if (n <= 0 || n > ARCVAE_PLANE_GROUP_MAX || M <= 0 || N <= 0 || (M % 128) || (N % 64) || rows <= 0 || (rows % 32) || ldc < N)
         return ARCVAE_ERR_ARG;
     PlaneTNGroup g;
@@ -1406,6 +1432,7 @@ int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* 
         if (!A[i] || !B[i] || !C[i] || nT[i] <= 0 || tA0[i] < 0 || tB0[i] < 0) return ARCVAE_ERR_ARG;
         PlaneTN& p = g.p[i];
         p.A = static_cast<const __bf16*>(A[i]); p.B = static_cast<const __bf16*>(B[i]); p.C = C[i];
+        p.colsum = colsum ? colsum[i] : nullptr;
         p.tA0 = tA0[i]; p.tB0 = tB0[i]; p.ksteps = nT[i] * (rows / 32);
         kmax = max(kmax, p.ksteps);
     }

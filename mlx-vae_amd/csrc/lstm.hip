@@ -3370,9 +3370,8 @@ extern "C" int arcvae_dense_stack_backward(const float* gates, const float* dh_t
         const void* Bp = w.hact_t + (long)(l - 1) * w.sHt;
         const int zero = 0, one = 1;
         float* Cp = dWx[l];
-        int rc = arcvae_wgrad_planes_group(1, G, H, Ri, &Ap, &zero, &Bp, &zero, &one, &Cp, H, stream);
-        if (rc) return rc;
-        rc = arcvae_colsum_accum(dG, Ri, G, G, dbias[l], 1.0f, stream);
+        float* Sp = dbias[l];
+        const int rc = arcvae_wgrad_planes_group(1, G, H, Ri, &Ap, &zero, &Bp, &zero, &one, &Cp, H, &Sp, stream);
         if (rc) return rc;
     }
     {   // dh0 = dG_1 . Wx_1
@@ -3484,11 +3483,11 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                     Bp[i] = static_cast<const char*>(h_oct) + 2 * ((long)lb * T * 3 * B * H);
                 }
                 for (int i = 0; i < n; i += 8) {
-                    rc = arcvae_wgrad_planes_group(n - i < 8 ? n - i : 8, G, H, B, Ap + i, ta + i, Bp + i, tb + i, nts + i, Cg + i, H, stream);
+                    // (the bias gradients ride in the GEMM: dbias_l += sum over rows of dG_l, a product with a column of ones)
+                    rc = arcvae_wgrad_planes_group(n - i < 8 ? n - i : 8, G, H, B, Ap + i, ta + i, Bp + i, tb + i, nts + i, Cg + i, H,
+                                                   Sg + i, stream);
                     if (rc) return rc;
                 }
-                for (int i = 0; i < n; ++i)
-                    if (Sg[i]) { rc = arcvae_colsum_accum(Ag[i], Kg[i], G, G, Sg[i], 1.0f, stream); if (rc) return rc; }
             } else if (b16 && h_oct && dG_oct && (B % 16) == 0) {
                 // throughput mode with the octet-major bf16 copies the tiled sweeps left (same ranges, same targets)
                 const void* Ao[2 * ARCVAE_MAX_LAYERS];

@@ -34,7 +34,8 @@ int arcvae_wgrad_octet_group(int n, int M, int N, const int* K, const void* cons
 
 // internal (C++ linkage): weight gradients of the tiled three-piece sweeps from their operand planes, see gemm.hip
 int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* A, const int* tA0, const void* const* B,
-                              const int* tB0, const int* nT, float* const* C, int ldc, hipStream_t stream);
+                              const int* tB0, const int* nT, float* const* C, int ldc, float* const* colsum /* optional */,
+                              hipStream_t stream);
 
 // internal (C++ linkage): a forward-only decoder layer (GEMM + zero-state cell, no pre-activations kept), see gemm.hip
 int arcvae_gemm_cell_zero(int M, int H, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
