@@ -1301,6 +1301,120 @@ template <int CH>
 void launch_bwd2(const BwdArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(lstm_bwd_step2_kernel<CH>, grid, dim3(1024), 0, s, a);
 }
+// The same kernel in the three-piece form (round 3): a third of a mid-batch BPTT launch is MATRIX time -- 64 exact-f32
+// instructions of 32 cycles per wave, four waves per SIMD: 3.5 us of a 10.7 us launch at 256 rows -- and it sits behind the
+// operand loads, on the chain.  With the operand copies as hi / mid / lo bf16 planes (the layout of the tiled sweeps:
+// [plane][k >> 5][row][32]) a wave's 64 k are two 32-wide chunks, six products each on v_mfma_f32_16x16x32_bf16: 48
+// instructions of 16 cycles, 1.3 us per launch; 1.5 x the operand bytes.  CH even (H % 128 == 0).  The epilogue writes the next
+// launches' planes.
+template <int CH>
+__global__ __launch_bounds__(1024) void lstm_bwd_step2s_kernel(BwdArgs a) {
+    static_assert(CH % 2 == 0, "two 16-wide chunks make one 32-wide plane chunk");
+    __shared__ float red[16 * 1024];  // [wave][32 rows][32 units]
+    arcvae_set_prio(a.prio);
+    const bool tr = a.trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    if (tr) a.trace[0] = wall_clock64();
+    if (a.signal && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const BwdJob& j = a.job[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H = a.H, G = 4 * a.H;
+    const int r0 = blockIdx.y * 32, u0 = blockIdx.x * 32;
+    const bool cell = j.kind == 0;
+    const int erow = tid >> 5, ecol = tid & 31;
+    const int eb = min(r0 + erow, B - 1);
+    const int unit = min(u0 + ecol, H - 1);
+    const long hb = (long)eb * H + unit;
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c_v = 0.f, cprev_v = 0.f, dcin_v = 0.f, ext_v = 0.f;
+    if (j.ext) ext_v = j.ext[(long)eb * j.ext_ld + unit];
+    if (cell) {
+        const float* gp = j.gates + (long)eb * G + unit;
+        gi = gp[0]; gf = gp[H]; gg = gp[2 * H]; go = gp[3 * H];
+        c_v = j.c[hb];
+        if (j.cprev) cprev_v = j.cprev[hb];
+        if (j.dcin) dcin_v = j.dcin[hb];
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j.src) {
+        constexpr int NC = CH / 2;                        // 32-wide chunks per wave
+        const int r = lane & 15, q8 = (lane >> 4) * 8;
+        const int arow[2] = {min(r0 + r, B - 1), min(r0 + 16 + r, B - 1)};
+        const int wrow[2] = {min(u0 + r, H - 1), min(u0 + 16 + r, H - 1)};
+        const __bf16* At = reinterpret_cast<const __bf16*>(j.src);
+        const __bf16* Wt = reinterpret_cast<const __bf16*>(j.WT);
+        const long pA = (long)B * G, pW = (long)H * G;
+        u32x4_l fa[3][2][NC], fw[3][2][NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const long kc = wave * NC + c;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    fa[p][m][c] = *reinterpret_cast<const u32x4_l*>(At + p * pA + (kc * B + arow[m]) * 32 + q8);
+                    fw[p][m][c] = *reinterpret_cast<const u32x4_l*>(Wt + p * pW + (kc * H + wrow[m]) * 32 + q8);
+                }
+        }
+#define STEP2_S3(PA, PW)                                                                                               \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)                    \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_l, fa[PA][m][c]),            \
+                                                                __builtin_bit_cast(bf16x8_l, fw[PW][n][c]), acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            STEP2_S3(0, 2) STEP2_S3(2, 0) STEP2_S3(1, 1) STEP2_S3(0, 1) STEP2_S3(1, 0) STEP2_S3(0, 0)
+        }
+#undef STEP2_S3
+    }
+    {
+        float* p = red + wave * 1024;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    p[(16 * m + (lane >> 4) * 4 + reg) * 32 + 16 * n + (lane & 15)] = acc[m][n][reg];
+    }
+    __syncthreads();
+    if (r0 + erow < B && u0 + ecol < H) {
+        float dh = ext_v;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) dh += red[w * 1024 + erow * 32 + ecol];
+        if (!cell) {
+            j.out[hb] = dh;
+        } else {
+            const float i = gi, f = gf, g = gg, o = go;
+            const float tc = tanhf(c_v);
+            const float d_o = dh * tc * o * (1.f - o);
+            const float dc = dh * o * (1.f - tc * tc) + dcin_v;
+            const float d_i = dc * g * i * (1.f - i);
+            const float d_f = j.cprev ? dc * cprev_v * f * (1.f - f) : 0.f;
+            const float d_g = dc * i * (1.f - g * g);
+            j.dcout[hb] = dc * f;
+            float* dp = j.out + (long)eb * G + unit;
+            dp[0] = d_i; dp[H] = d_f; dp[2 * H] = d_g; dp[3 * H] = d_o;
+            __bf16* tp = reinterpret_cast<__bf16*>(j.outt) + ((long)(unit >> 5) * B + eb) * 32 + (unit & 31);
+            const long gs = (long)(H >> 5) * B * 32, pl = (long)B * G;
+            const float dv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __bf16 p0, p1, p2;
+                split3_bf16(dv[q], p0, p1, p2);
+                tp[q * gs] = p0; tp[q * gs + pl] = p1; tp[q * gs + 2 * pl] = p2;
+            }
+        }
+    }
+    if (tr) a.trace[1] = wall_clock64();
+}
+template <int CH>
+void launch_bwd2s(const BwdArgs& a, dim3 grid, hipStream_t s) {
+    if constexpr (CH % 2 == 0) hipLaunchKernelGGL(lstm_bwd_step2s_kernel<CH>, grid, dim3(1024), 0, s, a);
+}
+
 // Mid-batch kernels when the batch is >= 256 rows (and the tiled form was not chosen).  ARCVAE_STEP_TILE=22 forces
 // them, 0 disables them together with the tiled kernels.
 inline bool choose_step2(int B) {
@@ -2685,8 +2799,18 @@ static inline bool bwd_bf16(int B, int H, int L, int flags) {
 static inline bool fwd_split3(int B, int H, int L, int flags) {
     return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) && fwd_tile_choice(B, H, L) != 0;
 }
+// ... and, OPT-IN (ARCVAE_STEP2_SPLIT3=1), the mid-batch 2x2 BPTT kernel where H is a multiple of 128.  Parity-green, measured
+// SLOWER than its exact-f32 form: 10.87 vs 10.64 us per launch alone at 256 rows (15.6 vs 14.2 in the step, 3.19 vs 3.03 ms),
+// 18.8 vs 17.1 at 512 -- the launch is bound by operand delivery and its stores, not by the 3.5 us of matrix time the form
+// removes (1.5 x the operand bytes, twelve 2-byte plane stores per element instead of four 4-byte ones).
+static inline bool bwd_step2_split3(int B, int H, int L) {
+    // (not where the opt-in output-split persistent BPTT would run instead: it reads the f32 weight layouts)
+    return choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) == 0 && choose_step2(B) && (H % 128) == 0 &&
+           !persist_bwd_shape_ok(B, 1, H, L) && arcvae_env_int("ARCVAE_STEP2_SPLIT3", 0) != 0;
+}
 static inline bool bwd_split3(int B, int H, int L, int flags) {
-    return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) && choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0;
+    return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) &&
+           (choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0 || bwd_step2_split3(B, H, L));
 }
 // Operand-plane weight gradients (gemm.hip: wgrad_planes_kernel): both sweeps on the three-piece tile kernels and whole
 // 32-row K-steps.  The operand rings (hseq_t, dG_t) then keep ALL T time slots -- the planes a launch writes for the next
@@ -3225,7 +3349,8 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         }
         if (step2) {
             dim3 grid2(ceil_div(H, 32), ceil_div(B, 32), nj);
-            DISPATCH_CH(H, launch_bwd2, a, grid2, stream)
+            if (s3) { DISPATCH_CH(H, launch_bwd2s, a, grid2, stream) }
+            else { DISPATCH_CH(H, launch_bwd2, a, grid2, stream) }
             continue;
         }
         dim3 grid(H / 16, ceil_div(B, 16), nj);
