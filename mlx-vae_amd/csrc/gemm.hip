@@ -1000,23 +1000,6 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
     // products, 64 x 64 tiles (61 KB of LDS).  For GEMMs that run BESIDE a persistent sweep: 2.7x less matrix-pipe time
     // than the exact-f32 form, in 32-cycle instead of 64-cycle instructions, on the SIMDs the chain's waves issue on.
     if ((flags & ARCVAE_GEMM_SPLIT3) && !(flags & ARCVAE_GEMM_BF16) && !(transA == 0 && M <= 256)) {
-        // 128 x 128 tiles (120 KB of LDS, ARCVAE_SPLIT3_TILE=128): half the operand bytes per output through L2 -> CU -- for the
-        // K-long weight-gradient shapes of the MFMA-bound regime, whose BPTT tile kernel holds no LDS
-        static const int tile3 = arcvae_env_int("ARCVAE_SPLIT3_TILE", 64);
-        if (tile3 == 128 && (flags & ARCVAE_GEMM_TILE128) && M >= 128 && N >= 128 && p.act == 0) {
-            dim3 g8(ceil_div(N, 128), ceil_div(M, 128), 1);
-            if (flags & ARCVAE_GEMM_SPLITK) {
-                static const int target8 = arcvae_env_int("ARCVAE_SPLIT3_BLOCKS", 256);
-                int z = min(ceil_div(target8, (int)(g8.x * g8.y)), max(1, K / 512));
-                if (z > 1) {
-                    p.kchunk = ceil_div(ceil_div(K, z), 64) * 64;
-                    g8.z = ceil_div(K, p.kchunk);
-                    if (!p.accumulate && arcvae_zero(C, M, N, ldc, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
-                }
-            }
-            if (launch_bf16_tile_t<128, 128, 32, 3>(p, g8, ak, bk, stream)) return arcvae_launch_status();
-            p.kchunk = ((K + BK - 1) / BK) * BK;
-        }
         dim3 grid(ceil_div(N, 64), ceil_div(M, 64), 1);
         if ((flags & ARCVAE_GEMM_SPLITK) && p.act == 0) {
             static const int target3 = arcvae_env_int("ARCVAE_SPLITK_BLOCKS", 512);
@@ -1027,7 +1010,8 @@ extern "C" int arcvae_gemm_f32(int transA, int transB, int M, int N, int K,
                 if (!p.accumulate && arcvae_zero(C, M, N, ldc, stream) != ARCVAE_OK) return ARCVAE_ERR_LAUNCH;
             }
         }
-        // (a 128 x 128 form -- 123 KB of LDS -- was built and dropped: no faster than the f32 128 x 128 tile where that is used,
+        // (a 128 x 128 form -- 123 KB of LDS -- was built and dropped twice: no faster than the f32 128 x 128 tile where that is used
+        // (round 2), 53 ms against 36 for the weight gradients of configs[2] (round 3: one block per CU, split and products in sequence),
         // and it cannot share a CU with a persistent sweep block, which is where this flag is for: the decoder's GEMMs waited
         // for the forward sweep to end, 0.98 -> 1.03 ms per step)
         if (launch_bf16_tile_t<64, 64, 32, 3>(p, grid, ak, bk, stream)) return arcvae_launch_status();
@@ -1173,7 +1157,7 @@ int arcvae_gemm_tn_group_accum(int n, int M, int N, const int* K, const float* c
         for (int i = 0; i < n; ++i) {
             if (K[i] <= 0) continue;
             const int rc = arcvae_gemm_f32(1, 0, M, N, K[i], A[i], lda, B[i], ldb, C[i], ldc, nullptr,
-                                           ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_SPLIT3 | ARCVAE_GEMM_TILE64 | ARCVAE_GEMM_TILE128, stream);
+                                           ARCVAE_GEMM_ACCUMULATE | ARCVAE_GEMM_SPLITK | ARCVAE_GEMM_SPLIT3 | ARCVAE_GEMM_TILE64, stream);
             if (rc) return rc;
         }
         return colsums_by_launch();
