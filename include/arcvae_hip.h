@@ -308,7 +308,8 @@ int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const fl
 int arcvae_dense_stack_ok(long R, int H, int L);
 int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats /* out */);
 int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws, long R,
-                               int H, int L, arcvae_stream_t stream);
+                               int H, int L, int flags /* bit 0: forward only (sampler): gates may be null, nothing the backward
+                               needs is written */, arcvae_stream_t stream);
 int arcvae_dense_stack_backward(const float* gates, const float* dh_top, float* dG, float* dh0, float* const* dWx,
                                 float* const* dbias, float* ws, long R, int H, int L, arcvae_stream_t stream);
 

@@ -256,9 +256,11 @@ def _dec_gemm_bits(ws) -> int:
 
 
 def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: int = 0,
-                          temperature: float = 1.0, keep_gpre: bool = True) -> None:
+                          temperature: float = 1.0, keep_gpre: bool = True, alone: bool = False) -> None:
     """models/decoder.py:152-175 for all B*V (row, token) pairs.  keep_gpre=False (sampler, loss-only forward): the layers'
-    pre-activations are not kept, so a layer's GEMM and cell run as one kernel (csrc/gemm.hip gemm_cell_zero_kernel)."""
+    pre-activations are not kept, so a layer's GEMM and cell run as one kernel (csrc/gemm.hip gemm_cell_zero_kernel).
+    alone=True (the sampler: no encoder sweep shares the chip) with ARCVAE_SAMPLER_TILED=1: layers 1 .. L-1 on the three-piece tile
+    kernel where its grid fills the chip (arcvae_dense_stack_forward, forward-only form)."""
     if not keep_gpre:
         mode |= _lib.DEC_NO_GPRE
     wx, _k1 = _layer_ptrs(dec, d.L, "Wx")
@@ -270,11 +272,25 @@ def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: in
              ptr(ws.lse), ptr(ws.nxt), ws.B, d.V, d.E, d.C, d.H, d.L, mode | bits | _dec_gemm_bits(ws),
              float(temperature), stream_ptr())
 
+    # (opt-in, ARCVAE_SAMPLER_TILED=1: parity-green, measured no faster than the fused exact-f32 GEMM + cell kernel -- 6.59 vs 6.63 ms
+    # per 10 k molecules: the split pass over hact[0] and the tile launch cost what the matrix time saves)
+    if alone and not keep_gpre and not (ws.bf16_parts & 2) and os.environ.get("ARCVAE_SAMPLER_TILED", "0") == "1" \
+            and _lib.load().arcvae_dense_stack_ok(ws.B * d.V, d.H, d.L) == 1:
+        if getattr(ws, "dense_ws_fwd", None) is None:
+            n = C.c_long(0)
+            _lib.load().arcvae_dense_stack_ws_floats(ws.B * d.V, d.H, d.L, C.byref(n))
+            ws.dense_ws_fwd = torch.empty(n.value, dtype=torch.float32, device=ws.hact.device)
+        mode &= ~_lib.DEC_NO_GPRE
+        part(_lib.DEC_PART_HEAD)
+        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), C.c_void_p(0), ptr(ws.dense_ws_fwd), ws.B * d.V, d.H, d.L, 1,
+             stream_ptr())
+        part(_lib.DEC_PART_TAIL)
+        return
     if keep_gpre and getattr(ws, "dense_ws", None) is not None:
         # MFMA-bound regime (StepEngine.workspace): layers 1 .. L-1 -- zero-state cells over B*V rows -- on the three-piece tile
         # kernels of the encoder's sweeps; `gpre` then holds the POST-activation gates (what their backward reads)
         part(_lib.DEC_PART_HEAD)
-        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), ptr(ws.gpre), ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, stream_ptr())
+        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), ptr(ws.gpre), ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, 0, stream_ptr())
         part(_lib.DEC_PART_TAIL)
         ws.dense_fwd = True
         return

@@ -53,6 +53,7 @@ struct FwdArgs {
     int B, H, V;
     int prio, remap;
     int dbg;                    // timing experiments only (ARCVAE_TILE_DEBUG, bf16 tile kernels): 1 no contraction, 2 no epilogue
+    int lite;                   // three-piece tile kernel, forward-only callers: bit 0 = the gates and c are not stored, bit 1 = nor the planes
     unsigned long long* trace;  // diagnostic: {start, end} of block (0,0,0) in 100 MHz ticks, or null
 };
 
@@ -599,13 +600,16 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
                 hv[k] = go[k] * tanhf(cc[k]);
             }
             const long hb = (long)row * H + unit;
-            float* gp = j.gates + (long)row * G + unit;
-            *reinterpret_cast<f32x4*>(gp) = gi;
-            *reinterpret_cast<f32x4*>(gp + H) = gf;
-            *reinterpret_cast<f32x4*>(gp + 2 * H) = gg;
-            *reinterpret_cast<f32x4*>(gp + 3 * H) = go;
             *reinterpret_cast<f32x4*>(j.h + hb) = hv;
-            *reinterpret_cast<f32x4*>(j.c + hb) = cc;
+            if (!(a.lite & 1)) {
+                float* gp = j.gates + (long)row * G + unit;
+                *reinterpret_cast<f32x4*>(gp) = gi;
+                *reinterpret_cast<f32x4*>(gp + H) = gf;
+                *reinterpret_cast<f32x4*>(gp + 2 * H) = gg;
+                *reinterpret_cast<f32x4*>(gp + 3 * H) = go;
+                *reinterpret_cast<f32x4*>(j.c + hb) = cc;
+            }
+            if (a.lite & 2) continue;
             __bf16 pc[3][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) split3_bf16(hv[k], pc[0][k], pc[1][k], pc[2][k]);
@@ -2903,7 +2907,7 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
     for (int s = 0; s < T + L - 1; ++s) {
         FwdArgs a;
         a.B = B; a.H = H; a.V = V; a.prio = arcvae_step_prio(); a.remap = arcvae_xcd_remap() | (arcvae_env_int("ARCVAE_TILE_XCD", 0) != 0 ? 2 : 0); a.trace = trace ? trace + 2 * (long)s : nullptr;
-        a.dbg = arcvae_env_int("ARCVAE_TILE_DEBUG", 0);
+        a.dbg = arcvae_env_int("ARCVAE_TILE_DEBUG", 0); a.lite = 0;
         int nj = 0;
         for (int l = 0; l < L; ++l) {
             const int t = s - l;
@@ -3424,9 +3428,12 @@ extern "C" int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats) 
 // hact [L, R, H]: layer 0 given (dec_l0_fwd_kernel), layers 1 .. L-1 written;  gates [L-1, R, 4H] POST-activation i, f, g, o of
 // layers 1 .. (what the backward below reads -- not the pre-activations arcvae_dec_forward_dense keeps);  Wx / bias: HOST arrays
 // [L] of device pointers (entry 0 unused).
+// flags bit 0: forward only (sampler) -- gates / cell states / the backward's weight planes / the top layer's planes are not written.
 extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws,
-                                          long R, int H, int L, hipStream_t stream) {
-    if (!Wx || !bias || !hact || !gates || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
+                                          long R, int H, int L, int flags, hipStream_t stream) {
+    if (!Wx || !bias || !hact || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
+    const bool fwd_only = (flags & 1) != 0;
+    if (!fwd_only && !gates) return ARCVAE_ERR_ARG;
     const int G = 4 * H, Ri = (int)R;
     const DenseWs w = dense_ws(ws, R, H, L);
     {   // weight planes, both layouts (arcvae_tile_weights modes 4 / 5)
@@ -3437,7 +3444,7 @@ extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* c
         for (int l = 1; l < L; ++l) {
             if (!Wx[l] || !bias[l]) return ARCVAE_ERR_ARG;
             src[n] = Wx[l]; dst[n] = w.wt + (l - 1) * w.wsz; cols[n] = H; mode[n] = 4; ++n;
-            src[n] = Wx[l]; dst[n] = w.wT + (l - 1) * w.wsz; cols[n] = H; mode[n] = 5; ++n;
+            if (!fwd_only) { src[n] = Wx[l]; dst[n] = w.wT + (l - 1) * w.wsz; cols[n] = H; mode[n] = 5; ++n; }
         }
         const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
@@ -3447,6 +3454,7 @@ extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* c
     for (int l = 1; l < L; ++l) {
         FwdArgs a;
         a.B = Ri; a.H = H; a.V = 1; a.prio = 0; a.remap = 0; a.trace = nullptr; a.dbg = 0;
+        a.lite = fwd_only ? (l == L - 1 ? 3 : 1) : 0;
         FwdJob& j = a.job[0];
         j.xin = w.hact_t + (long)(l - 1) * w.sHt; j.Wx = w.wt + (l - 1) * w.wsz;
         j.hprev = nullptr; j.Wh = nullptr;
@@ -3454,7 +3462,7 @@ extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* c
         j.h = hact + (long)l * R * H;
         j.ht = w.hact_t + (long)l * w.sHt;
         j.c = w.cseq + (long)(l - 1) * R * H;
-        j.gates = gates + (long)(l - 1) * R * G;
+        j.gates = gates ? gates + (long)(l - 1) * R * G : nullptr;
         j.oct = nullptr;
         for (int k = 1; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
         launch_fwd_tile<4, 4, 2>(a, Ri, H, 1, stream);

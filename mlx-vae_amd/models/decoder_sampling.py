@@ -50,7 +50,7 @@ class MLXAutoregressiveDecoderSampling:
         st = self._graphs[key]
 
         def enqueue():
-            E.decoder_forward_dense(dec.store, ws, dec.dims, mode=1, temperature=temperature, keep_gpre=False)
+            E.decoder_forward_dense(dec.store, ws, dec.dims, mode=1, temperature=temperature, keep_gpre=False, alone=True)
             call("arcvae_dec_sample_chain", ptr(ws.nxt), ptr(st["tokens"]), ptr(st["first_end"]), B, dec.vocab_size,
                  max_length, dec.end_token, stream_ptr())
 

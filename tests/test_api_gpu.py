@@ -160,6 +160,25 @@ def test_generate_matches_reference_sampler(early):
     assert out.shape[0] == B and out.shape[1] <= 16
 
 
+def test_generate_on_the_tile_kernel_matches_reference_sampler(monkeypatch):
+    """The sampler's decode pass with layers 1 .. L-1 on the three-piece tile kernel (arcvae_dense_stack_forward, forward-only
+    form; opt-in), forced on at a small shape (B*V a multiple of 32): tokens against the oracle's sampler."""
+    monkeypatch.setenv("ARCVAE_DENSE_TILED", "2")
+    monkeypatch.setenv("ARCVAE_SAMPLER_TILED", "1")      # (opt-in: measured no faster than the fused f32 kernel at bs 1024)
+    cfg, B = TINY, 32
+    params = O.init_params(cfg, 1234)
+    vae = _vae(cfg, params)
+    vae.decoder_sampling.load_from_decoder(vae.decoder)
+    cond = np.random.RandomState(9).standard_normal((B, cfg.C)).astype(np.float32)
+    pd = {k[len("decoder."):]: torch.tensor(v) for k, v in params.items() if k.startswith("decoder.")}
+    ref = O.generate_with_temperature(pd, torch.tensor(cond), cfg.L, max_length=30, temperature=1.0, early_stopping=False).numpy()
+    for _ in range(2):
+        got = vae.decoder_sampling.generate_with_temperature(torch.zeros(B, cfg.Z), cond, max_length=30, temperature=1.0,
+                                                             early_stopping=False)
+        assert np.array_equal(got.cpu().numpy(), ref)
+    assert (B * cfg.V) % 32 == 0
+
+
 @pytest.mark.parametrize("max_length", [80, 128])
 def test_generate_at_config5_size_matches_reference_sampler(max_length):
     """BASELINE.json configs[4]: default model, bs 1024, max_length 80 (API default) and 128 -- tokens against the
