@@ -771,7 +771,7 @@ def roofline_probe(eng, ws, torch):
     if fused:
         flops_total *= 2.0    # + dWh_l += dG_l^T.h_l[t-1] (L(T-1) of them) and dWx_l += dG_l^T.h_{l-1}[t] ((L-1)T): same count
     ach = flops_total / launches / (us * 1e-6) / 1e12
-    tiled = (not persistent) and bool(_lib_load().arcvae_enc_lstm_tiled(B, d.H, d.L) & 2)
+    tiled = (not persistent) and bool(_lib_load().arcvae_enc_lstm_tiled_for(B, d.H, d.L, E._lstm_flags(ws)) & 2)
     bf16 = getattr(eng, "precision", "fp32") == "bf16" and (persistent or tiled)   # the sweep really runs bf16 blocks / tiles
     kernel = ("lstm_bwd_persist_rs_kernel" if persistent else
               (("lstm_bwd_tile_ks_kernel" if bf16 else "lstm_bwd_tile_ks3_kernel / lstm_bwd_tile_kernel") if tiled else

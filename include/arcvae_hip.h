@@ -107,6 +107,9 @@ int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const floa
 /* bit 0 / bit 1: the forward / backward sweep of this shape runs on the register-tiled step kernels, i.e. ARCVAE_LSTM_BF16
  * takes effect there and h_oct / dG_oct get written (pass them to arcvae_enc_lstm_wgrad only when both bits are set). */
 int arcvae_enc_lstm_tiled(int B, int H, int L);
+/* The same for sweeps called with `flags`: with ARCVAE_LSTM_SPLIT3 (the three-piece form, what the engine passes on the parity path)
+ * the tile regime starts at smaller grids -- from ~768 rows per GPU at H 256 / L 2 instead of ~1100. */
+int arcvae_enc_lstm_tiled_for(int B, int H, int L, int flags);
 /* Time slots of the operand rings hseq_t [L,slots,..] / dG_t [L,slots,..] the sweeps use for this shape with these flags: T where
  * the weight gradients read the operand planes (both sweeps on the three-piece tile kernels, B % 32 == 0: pass the rings to
  * arcvae_enc_lstm_wgrad with parts bit 11), else min(T, 16).  The dc / dX rings always have min(T, 16) slots. */

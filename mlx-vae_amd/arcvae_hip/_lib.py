@@ -47,6 +47,7 @@ SIGNATURES = {
     "arcvae_transpose_tokens": [_vp, _vp, _i, _i, _vp],
     "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "arcvae_enc_lstm_tiled": [_i, _i, _i],
+    "arcvae_enc_lstm_tiled_for": [_i, _i, _i, _i],
     "arcvae_enc_lstm_operand_slots": [_i, _i, _i, _i, _i],
     "arcvae_dense_stack_ok": [_l, _i, _i],
     "arcvae_dense_stack_ws_floats": [_l, _i, _i, _lp],

@@ -577,7 +577,7 @@ class EncoderBackwardPlan:
                  t_lo, t_hi, int(first), int(last), parts, ptr(ws.hseq_t), ptr(ws.dG_t), stream_ptr())
             return
         elif (not self.persistent and os.environ.get("ARCVAE_WGRAD_SPLIT3", "1") != "0"
-              and (_lib.load().arcvae_enc_lstm_tiled(ws.B, d.H, d.L) & 2)):
+              and (_lib.load().arcvae_enc_lstm_tiled_for(ws.B, d.H, d.L, _lstm_flags(ws)) & 2)):
             # MFMA-bound regime (the BPTT runs on the register-tiled kernels): the weight-gradient GEMMs as three-piece tile
             # GEMMs -- 2.7x less matrix-pipe time at fp32-class accuracy (bs 2048: 22.3 -> 21.3 ms, configs[2]: 42.0 -> 40.9;
             # at 128 / 256 rows, beside the persistent or 2x2 sweeps, the exact-f32 tile GEMM stays ahead: 1.705 vs 1.777, 3.24 vs 3.52)
@@ -689,7 +689,7 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
     # (ARCVAE_WX_ON_SIDE=0/1 overrides).
     # (round 3: also with the mid-batch step kernels from 256 rows per GPU on -- bs 256: 3.081 -> 3.042 ms, bs 512: 6.47 -> 6.27;
     # no difference at 160 / 192 rows)
-    mid_batch = ws is not None and ws.B >= 256 and not (_lib.load().arcvae_enc_lstm_tiled(ws.B, plan.d.H, plan.d.L) & 2)
+    mid_batch = ws is not None and ws.B >= 256 and not (_lib.load().arcvae_enc_lstm_tiled_for(ws.B, plan.d.H, plan.d.L, _lstm_flags(ws)) & 2)
     wx_on_side = table_on_side and os.environ.get("ARCVAE_WX_ON_SIDE", "1" if (plan.persistent or mid_batch) else "0") != "0"
     # Round 2: the token-table path is linear, so every chunk folds its OWN table (zero, one-hot GEMM, fold: first = last
     # = True) -- and the LAST chunk's, the only one in the exposed tail, is formed by main itself right behind the sweep
@@ -916,7 +916,7 @@ class StepEngine:
             ws.dec_split3 = os.environ.get("ARCVAE_DEC_SPLIT3", "1" if (B <= 64 and persistent_forward_ok(ws, self.d)) else "0") == "1"
             ws.bf16_parts = int(os.environ.get("ARCVAE_BF16_PARTS", "7")) if ws.bf16 else 0   # ablation: 1 sweeps, 2 decoder, 4 weight gradients
             if (train and (ws.bf16_parts & 5) == 5 and B % 16 == 0 and os.environ.get("ARCVAE_BF16_OCT", "1") != "0"
-                    and _lib.load().arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3
+                    and _lib.load().arcvae_enc_lstm_tiled_for(B, self.d.H, self.d.L, _lstm_flags(ws)) == 3
                     and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)
                     and _lib.load().arcvae_enc_lstm_bwd_persistent_ok(B, T, self.d.H, self.d.L) != 1):
                 # bf16 copies of hseq / dG in the weight-gradient kernel's operand layout, written by the tiled sweeps
@@ -937,13 +937,13 @@ class StepEngine:
             ws.dense_ws = None
             dense_force = os.environ.get("ARCVAE_DENSE_TILED", "1") == "2"
             if (train and not ws.bf16 and lib.arcvae_dense_stack_ok(B * self.d.V, self.d.H, self.d.L) == 1
-                    and (dense_force or (lib.arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3
+                    and (dense_force or (lib.arcvae_enc_lstm_tiled_for(B, self.d.H, self.d.L, _lstm_flags(ws)) == 3
                                          and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)))):
                 n = C.c_long(0)
                 lib.arcvae_dense_stack_ws_floats(B * self.d.V, self.d.H, self.d.L, C.byref(n))
                 ws.dense_ws = torch.empty(n.value, dtype=torch.float32, device=self.device)
             ws.planes = bool(train and slots == T and _lstm_flags(ws) == _lib.LSTM_SPLIT3 and B % 32 == 0
-                             and lib.arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) == 3
+                             and lib.arcvae_enc_lstm_tiled_for(B, self.d.H, self.d.L, _lstm_flags(ws)) == 3
                              and os.environ.get("ARCVAE_WGRAD_PLANES", "1") != "0"
                              and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)
                              and lib.arcvae_enc_lstm_bwd_persistent_ok(B, T, self.d.H, self.d.L) != 1)
@@ -955,7 +955,7 @@ class StepEngine:
             ws.pl_h = ws.pl_g = None
             conv = os.environ.get("ARCVAE_WGRAD_CONVERT", "0")
             if (train and not ws.planes and not ws.bf16 and B % 32 == 0 and self.d.H % 64 == 0 and conv != "0"
-                    and (conv == "2" or B >= 256) and not (lib.arcvae_enc_lstm_tiled(B, self.d.H, self.d.L) & 2)
+                    and (conv == "2" or B >= 256) and not (lib.arcvae_enc_lstm_tiled_for(B, self.d.H, self.d.L, _lstm_flags(ws)) & 2)
                     and not bptt_reduce_scatter_ok(ws, self.d)):
                 ws.pl_h = torch.empty(self.d.L * T * B * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
                 ws.pl_g = torch.empty(self.d.L * T * B * 4 * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)

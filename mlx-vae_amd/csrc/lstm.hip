@@ -1072,16 +1072,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_ks3_kernel(BwdArgs a) {
     if (tr) a.trace[1] = wall_clock64();
 }
 
-// Largest register tile whose grid still fills the chip (>= 200 blocks), or 0 = keep the latency-oriented 16x16
-// kernels.  ARCVAE_STEP_TILE: -1 auto (default), 0 never, 1 / 2 / 4 force that MT.
-inline int choose_tile_mt(int B, int col_blocks, int jobs) {
+// Largest register tile whose grid still fills the chip (>= minb blocks: 200; 140 in the three-piece form, see
+// tile_min_blocks), or 0 = keep the latency-oriented 16x16 kernels.  ARCVAE_STEP_TILE: -1 auto (default), 0 never, 1 / 2 / 4
+// force that MT.
+inline int choose_tile_mt(int B, int col_blocks, int jobs, int minb = 200) {
     const int force = arcvae_env_int("ARCVAE_STEP_TILE", -1);  // read per sweep call (tests toggle it)
     if (force == 0 || force == 22) return 0;
     if (force == 1 || force == 2 || force == 4) return force;
     if (force == 44) return 4;
     const int mts[2] = {4, 2};  // MT = 1 never pays: at that size the all-loads-first 16x16 kernels are ahead
     for (int i = 0; i < 2; ++i)
-        if (ceil_div(B, 16 * mts[i]) * col_blocks * jobs >= 200) return mts[i];
+        if (ceil_div(B, 16 * mts[i]) * col_blocks * jobs >= minb) return mts[i];
     return 0;
 }
 
@@ -2787,34 +2788,52 @@ inline bool hidden_ok(int H) { return H > 0 && (H % 64) == 0 && H <= 512; }
 // Throughput mode (ARCVAE_LSTM_BF16): the sweeps' operand copies and products in bf16 -- where the shape runs on the
 // register-tiled step kernels (the MFMA-bound regime, BASELINE.json configs[2]); the latency-regime kernels stay f32 (a
 // tick there is round trips, not matrix time: DESIGN.md section 10).  Forward and BPTT decide separately (their grids differ).
-static inline int fwd_tile_choice(int B, int H, int L) {
-    int tile_mt = choose_tile_mt(B, H / 32, L);
+// Where the tile regime starts.  With the three-piece form and what round 3 built on it (K-split BPTT tile, weight gradients
+// from the operand planes, the dense decoder on the same kernels) the whole step is ahead of the mid-batch kernels from grids
+// of ~140 blocks on -- measured at H 256 / L 2: 640 rows 7.96 vs 7.69 ms (120 blocks: not yet), 768 rows 8.40 vs 8.82, 896 rows
+// 9.03 vs 10.09, 1024 rows 9.43 vs 10.94 (192 blocks).  The exact-f32 and throughput-mode forms keep the 200 they were tuned
+// with.  ARCVAE_S3_MIN_BLOCKS overrides.
+static inline bool s3_flags(int flags) { return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16); }
+static inline int tile_min_blocks(int flags) { return s3_flags(flags) ? arcvae_env_int("ARCVAE_S3_MIN_BLOCKS", 140) : 200; }
+static inline int fwd_tile_choice(int B, int H, int L, int flags) {
+    // (the earlier start only together with the BPTT's: a 64-row forward tile on a 160-block grid beside the mid-batch BPTT kernels
+    // loses to the 32-row tile -- 640 rows: 8.04 vs 7.69 ms)
+    const bool early = s3_flags(flags) && arcvae_env_int("ARCVAE_STEP_TILE", -1) < 0 &&
+                       (H / 64) * ceil_div(B, 64) * (2 * L - 1) >= tile_min_blocks(flags);
+    int tile_mt = choose_tile_mt(B, H / 32, L, early ? tile_min_blocks(flags) : 200);
     const int tile_env = arcvae_env_int("ARCVAE_STEP_TILE", -1);
     if (tile_env == 44 || (tile_mt == 4 && tile_env != 4 && ceil_div(B, 64) * (H / 64) * L >= 200))
         tile_mt = 44;  // the 64 x 64 wave tile (16 FLOP per byte) when even its grid fills the chip; 44 forces it
     return tile_mt;
 }
-static inline bool fwd_bf16(int B, int H, int L, int flags) { return (flags & ARCVAE_LSTM_BF16) && fwd_tile_choice(B, H, L) != 0; }
+// BPTT: in the three-piece form the K-split 64 x 64 tile decides (its grid: H/64 x ceil(B/64) x jobs); else the 64 x 32 wave tile's
+static inline int bwd_tile_choice(int B, int H, int L, int flags) {
+    if (s3_flags(flags)) {
+        const int force = arcvae_env_int("ARCVAE_STEP_TILE", -1);
+        if (force < 0 && (H / 64) * ceil_div(B, 64) * (2 * L - 1) >= tile_min_blocks(flags)) return 4;
+    }
+    return choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1);
+}
+static inline bool fwd_bf16(int B, int H, int L, int flags) { return (flags & ARCVAE_LSTM_BF16) && fwd_tile_choice(B, H, L, flags) != 0; }
 static inline bool bwd_bf16(int B, int H, int L, int flags) {
-    return (flags & ARCVAE_LSTM_BF16) && choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0;
+    return (flags & ARCVAE_LSTM_BF16) && bwd_tile_choice(B, H, L, flags) != 0;
 }
 // Three-piece form (ARCVAE_LSTM_SPLIT3, a parity path): where the sweep runs on the register-tiled kernels and the
 // throughput mode is not asked for.  The operand copies then hold three bf16 planes: 1.5 x the f32 copies' size.
 static inline bool fwd_split3(int B, int H, int L, int flags) {
-    return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) && fwd_tile_choice(B, H, L) != 0;
+    return s3_flags(flags) && fwd_tile_choice(B, H, L, flags) != 0;
 }
 // ... and, OPT-IN (ARCVAE_STEP2_SPLIT3=1), the mid-batch 2x2 BPTT kernel where H is a multiple of 128.  Parity-green, measured
 // SLOWER than its exact-f32 form: 10.87 vs 10.64 us per launch alone at 256 rows (15.6 vs 14.2 in the step, 3.19 vs 3.03 ms),
 // 18.8 vs 17.1 at 512 -- the launch is bound by operand delivery and its stores, not by the 3.5 us of matrix time the form
 // removes (1.5 x the operand bytes, twelve 2-byte plane stores per element instead of four 4-byte ones).
-static inline bool bwd_step2_split3(int B, int H, int L) {
+static inline bool bwd_step2_split3(int B, int H, int L, int flags) {
     // (not where the opt-in output-split persistent BPTT would run instead: it reads the f32 weight layouts)
-    return choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) == 0 && choose_step2(B) && (H % 128) == 0 &&
+    return bwd_tile_choice(B, H, L, flags) == 0 && choose_step2(B) && (H % 128) == 0 &&
            !persist_bwd_shape_ok(B, 1, H, L) && arcvae_env_int("ARCVAE_STEP2_SPLIT3", 0) != 0;
 }
 static inline bool bwd_split3(int B, int H, int L, int flags) {
-    return (flags & ARCVAE_LSTM_SPLIT3) && !(flags & ARCVAE_LSTM_BF16) &&
-           (choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0 || bwd_step2_split3(B, H, L));
+    return s3_flags(flags) && (bwd_tile_choice(B, H, L, flags) != 0 || bwd_step2_split3(B, H, L, flags));
 }
 // Operand-plane weight gradients (gemm.hip: wgrad_planes_kernel): both sweeps on the three-piece tile kernels and whole
 // 32-row K-steps.  The operand rings (hseq_t, dG_t) then keep ALL T time slots -- the planes a launch writes for the next
@@ -2867,7 +2886,12 @@ extern "C" int arcvae_enc_lstm_operand_slots(int B, int T, int H, int L, int fla
 
 extern "C" int arcvae_enc_lstm_tiled(int B, int H, int L) {
     if (B <= 0 || L <= 0 || !hidden_ok(H)) return 0;
-    return (fwd_tile_choice(B, H, L) != 0 ? 1 : 0) | (choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1) != 0 ? 2 : 0);
+    return (fwd_tile_choice(B, H, L, 0) != 0 ? 1 : 0) | (bwd_tile_choice(B, H, L, 0) != 0 ? 2 : 0);
+}
+// ... for the sweeps called with these flags (the three-piece form enters the tile regime earlier: tile_min_blocks)
+extern "C" int arcvae_enc_lstm_tiled_for(int B, int H, int L, int flags) {
+    if (B <= 0 || L <= 0 || !hidden_ok(H)) return 0;
+    return (fwd_tile_choice(B, H, L, flags) != 0 ? 1 : 0) | (bwd_tile_choice(B, H, L, flags) != 0 ? 2 : 0);
 }
 
 // Reference: models/encoder.py:98-101 (L stacked nn.LSTM over the full padded sequence, Q3).
@@ -2900,7 +2924,7 @@ extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0,
                                         bwd_split3(B, H, L, flags) ? 2 : (bwd_bf16(B, H, L, flags) ? 1 : 0), stream);
         if (rc != ARCVAE_OK) return rc;
     }
-    const int tile_mt = fwd_tile_choice(B, H, L);
+    const int tile_mt = fwd_tile_choice(B, H, L, flags);
     const bool oct = b16 && h_oct && (B % 16) == 0;      // the octet-major copy groups 8 batch rows of one time step
     const bool step2 = !tile_mt && choose_step2(B);
     const int RS = operand_ring_slots(B, T, H, L, flags);
@@ -3276,7 +3300,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
         const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
     }
-    const int tile_mt = choose_tile_mt(B, ceil_div(H, 128), 2 * L - 1);
+    const int tile_mt = bwd_tile_choice(B, H, L, flags);
     const bool step2 = !tile_mt && choose_step2(B);
     const int RS = arcvae_ring_slots(T), RSo = operand_ring_slots(B, T, H, L, flags);   // dc / dX rings, operand-plane ring
     for (int s = s_begin; s < s_end; ++s) {
@@ -3330,7 +3354,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 // ARCVAE_BWD_KSPLIT3 (default 1; 2 forces it: tests): the K-split 64 x 64 three-piece form where its grid fills the chip (its
                 // 16-byte epilogue accesses need dh_top on a 16-byte grid)
                 const int ks3 = arcvae_env_int("ARCVAE_BWD_KSPLIT3", 1);   // (read per call: tests toggle it)
-                if (ks3 != 0 && (ks3 == 2 || (H / 64) * ceil_div(B, 64) * nj >= 200) && (ld_dh_top % 4) == 0 &&
+                if (ks3 != 0 && (ks3 == 2 || (H / 64) * ceil_div(B, 64) * nj >= tile_min_blocks(flags)) && (ld_dh_top % 4) == 0 &&
                     (reinterpret_cast<uintptr_t>(dh_top) % 16) == 0) {
                     hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 64 * 1024, stream, a);
                     continue;
