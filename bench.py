@@ -788,7 +788,7 @@ def roofline_probe(eng, ws, torch):
     pmc = newest("r*_pmc_summary.json")
     if pmc:
         try:
-            ent = json.load(open(pmc)).get(kernel, {})
+            ent = json.load(open(pmc)).get(kernel.split(" / ")[0], {})   # (a family is looked up by its first, dominant member)
             traffic = ent.get("bytes_per_tick", ent.get("bytes_per_launch"))
             traffic_source = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc, separate passes; not measured in this run)"
         except Exception:
