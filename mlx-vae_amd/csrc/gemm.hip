@@ -1342,6 +1342,7 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");       // (compiler fence: no LDS read of this K-step may be scheduled above the barrier)
         if (loader && ks + 2 < kend && !(g.dbg & 4)) issue(ks + 2, cur == 0 ? 2 : cur - 1);         // (the stage read at ks - 1)
         if (!loader && active && !(g.dbg & 2)) {
             // A fragments of the K-step stay in registers (48); the B fragments come one 16-column tile at a time (12): the
