@@ -9,7 +9,7 @@ timeout -k 10 120 python tools/phase_times.py > gpurun_out/phase_$TAG.txt 2>&1; 
 timeout -k 10 200 python tools/bench_sampler.py > gpurun_out/sampler_$TAG.json 2> gpurun_out/sampler_$TAG.err; echo "sampler rc=$?"
 timeout -k 10 200 python tools/epoch_time.py > gpurun_out/epoch_$TAG.txt 2>&1; echo "epoch rc=$?"
 rm -f gpurun_out/bench_extra_$TAG.jsonl
-for a in "--batch-per-gpu 128" "--batch-per-gpu 256" "--batch-per-gpu 2048 --steps 30 --warmup 5" "--config big --steps 30 --warmup 5" "--force-dp"; do
+for a in "--batch-per-gpu 128" "--batch-per-gpu 256" "--batch-per-gpu 512 --steps 60 --warmup 10" "--batch-per-gpu 1024 --steps 40 --warmup 8" "--batch-per-gpu 2048 --steps 30 --warmup 5" "--config big --steps 30 --warmup 5" "--force-dp"; do
   timeout -k 10 200 python bench.py --cpu-steps 0 --strong-global-batch 0 --bf16-steps 0 --configs2-steps 0 --sampler-reps 0 $a 2>/dev/null >> gpurun_out/bench_extra_$TAG.jsonl; echo "extra [$a] rc=$?"
 done
 timeout -k 10 120 python tools/bench_planes.py > gpurun_out/planes_$TAG.txt 2>&1; echo "planes rc=$?"
