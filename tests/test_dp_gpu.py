@@ -119,6 +119,20 @@ def test_two_ranks_late_reduce_form(monkeypatch):
     _compare_with_single_process("tiny", B, T, ret)
 
 
+@pytest.mark.timeout(600)
+def test_two_ranks_in_the_tile_regime(monkeypatch):
+    """The MFMA-bound regime's machinery under the data-parallel step (what a rank of a 2-GPU run of configs[3] executes at 1024
+    rows): three-piece tile sweeps, K-split BPTT tile, weight gradients from the operand planes with the bias rider, dense decoder
+    layers on the tile kernels -- forced on at 2 x 32 rows, against one process on 64 rows."""
+    for k, v in (("ARCVAE_STEP_TILE", "4"), ("ARCVAE_BWD_KSPLIT3", "2"), ("ARCVAE_DENSE_TILED", "2"), ("ARCVAE_PERSIST", "0")):
+        monkeypatch.setenv(k, v)
+    world, B, T = 2, 64, 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), "tiny", B, T, ret), nprocs=world, join=True)
+    _compare_with_single_process("tiny", B, T, ret)
+
+
 @pytest.mark.timeout(900)
 def test_two_ranks_persistent_sweeps_under_the_collectives():
     """H = 256, L = 2 (the default model's recurrence): persistent forward sweep, persistent reduce-scatter BPTT, gates
