@@ -311,10 +311,12 @@ int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const fl
 int arcvae_dense_stack_ok(long R, int H, int L);
 int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats /* out */);
 int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws, long R,
-                               int H, int L, int flags /* bit 0: forward only (sampler): gates may be null, nothing the backward
-                               needs is written */, arcvae_stream_t stream);
+                               int H, int L, int flags /* bit 0: forward only (sampler): nothing the backward needs is written;
+                               ARCVAE_LSTM_BF16 (bit 1): throughput mode -- bf16 operand copies, one product (not a parity path) */,
+                               arcvae_stream_t stream);
 int arcvae_dense_stack_backward(const float* gates, const float* dh_top, float* dG, float* dh0, float* const* dWx,
-                                float* const* dbias, float* ws, long R, int H, int L, arcvae_stream_t stream);
+                                float* const* dbias, float* ws, long R, int H, int L, int flags /* ARCVAE_LSTM_BF16 or 0: as the
+                                forward was called */, arcvae_stream_t stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------------
  * trainer.py:75-76,320,324: MLX optim.Adam, NO bias correction (Q7):

@@ -52,7 +52,7 @@ SIGNATURES = {
     "arcvae_dense_stack_ok": [_l, _i, _i],
     "arcvae_dense_stack_ws_floats": [_l, _i, _i, _lp],
     "arcvae_dense_stack_forward": [_pp, _pp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
-    "arcvae_dense_stack_backward": [_vp, _vp, _vp, _vp, _pp, _pp, _vp, _l, _i, _i, _vp],
+    "arcvae_dense_stack_backward": [_vp, _vp, _vp, _vp, _pp, _pp, _vp, _l, _i, _i, _i, _vp],
     "arcvae_enc_lstm_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_prologue": [_vp, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

@@ -290,7 +290,8 @@ def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: in
         # MFMA-bound regime (StepEngine.workspace): layers 1 .. L-1 -- zero-state cells over B*V rows -- on the three-piece tile
         # kernels of the encoder's sweeps; `gpre` then holds the POST-activation gates (what their backward reads)
         part(_lib.DEC_PART_HEAD)
-        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), ptr(ws.gpre), ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, 0, stream_ptr())
+        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), ptr(ws.gpre), ptr(ws.dense_ws), ws.B * d.V, d.H, d.L,
+             _lib.LSTM_BF16 if (ws.bf16_parts & 2) else 0, stream_ptr())
         part(_lib.DEC_PART_TAIL)
         ws.dense_fwd = True
         return
@@ -324,7 +325,7 @@ def decoder_backward(dec: ParamStore, ws: Workspace, d: ModelDims, inv_count: fl
         # backward on the same kernels (dh_top in ddh[0] -> dh_0 in ddh[1]), then layer 0 and the token table
         part(_lib.DEC_PART_TAIL, ptr(ws.ddh))
         call("arcvae_dense_stack_backward", ptr(ws.gpre), ptr(ws.ddh[0]), ptr(ws.ddG), ptr(ws.ddh[1]), dwx, dbs,
-             ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, s)
+             ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, _lib.LSTM_BF16 if (ws.bf16_parts & 2) else 0, s)
         part(_lib.DEC_PART_HEAD, ptr(ws.ddh[1]))
         return
     part(0, ptr(ws.ddh))
@@ -936,7 +937,9 @@ class StepEngine:
             # blocks -- 370-420 registers, 64-70 KB of LDS -- cannot be resident and the two serialise: bs 128 1.63 -> 2.00 ms)
             ws.dense_ws = None
             dense_force = os.environ.get("ARCVAE_DENSE_TILED", "1") == "2"
-            if (train and not ws.bf16 and lib.arcvae_dense_stack_ok(B * self.d.V, self.d.H, self.d.L) == 1
+            # (throughput mode: the same stack on the bf16 tile kernels and the octet weight-gradient kernel, where its decoder and
+            # sweep parts are both on: ARCVAE_BF16_PARTS bits 0 and 1)
+            if (train and (not ws.bf16 or (ws.bf16_parts & 3) == 3) and lib.arcvae_dense_stack_ok(B * self.d.V, self.d.H, self.d.L) == 1
                     and (dense_force or (lib.arcvae_enc_lstm_tiled_for(B, self.d.H, self.d.L, _lstm_flags(ws)) == 3
                                          and not persistent_forward_ok(ws, self.d) and not bptt_reduce_scatter_ok(ws, self.d)))):
                 n = C.c_long(0)

@@ -3415,8 +3415,19 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
 #pragma unroll
     for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<bf16x4_l*>(tp + pz * R * H) = bf16x4_l{pc[pz][0], pc[pz][1], pc[pz][2], pc[pz][3]};
 }
+__global__ __launch_bounds__(256) void bf16_copies_from_f32_kernel(const float* __restrict__ X, __bf16* __restrict__ P,
+                                                                   __bf16* __restrict__ O8, long R, int H) {
+    // throughput mode: X [R, H] f32 -> the tile kernels' operand copy [H >> 5][R][32] and the octet-major copy [R >> 3][H][8]
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * H) return;
+    const long row = i / H;
+    const int unit = (int)(i - row * H);
+    const __bf16 v = to_bf16(X[i]);
+    P[((long)(unit >> 5) * R + row) * 32 + (unit & 31)] = v;
+    O8[((row >> 3) * H + unit) * 8 + (row & 7)] = v;
+}
 struct DenseWs {
-    float *hact_t, *cseq, *dG_t, *dc, *wt, *wT;
+    float *hact_t, *cseq, *dG_t, *dc, *wt, *wT, *oct_h, *oct_g;   // (oct_*: throughput mode's octet-major bf16 copies)
     long sHt, sGt, wsz, total;
 };
 inline DenseWs dense_ws(float* base, long R, int H, int L) {
@@ -3430,6 +3441,8 @@ inline DenseWs dense_ws(float* base, long R, int H, int L) {
     w.dc = base + o; o += R * H;
     w.wt = base + o; o += (long)(L - 1) * w.wsz;
     w.wT = base + o; o += (long)(L - 1) * w.wsz;
+    w.oct_h = base + o; o += (long)L * R * H / 2;
+    w.oct_g = base + o; o += R * G / 2;
     w.total = o;
     return w;
 }
@@ -3456,8 +3469,8 @@ extern "C" int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats) 
 extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws,
                                           long R, int H, int L, int flags, hipStream_t stream) {
     if (!Wx || !bias || !hact || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
-    const bool fwd_only = (flags & 1) != 0;
-    if (!fwd_only && !gates) return ARCVAE_ERR_ARG;
+    const bool fwd_only = (flags & 1) != 0, b16 = (flags & ARCVAE_LSTM_BF16) != 0;   // bit 1: throughput mode (bf16 operands)
+    if ((!fwd_only && !gates) || (fwd_only && b16)) return ARCVAE_ERR_ARG;
     const int G = 4 * H, Ri = (int)R;
     const DenseWs w = dense_ws(ws, R, H, L);
     {   // weight planes, both layouts (arcvae_tile_weights modes 4 / 5)
@@ -3467,12 +3480,16 @@ extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* c
         int n = 0;
         for (int l = 1; l < L; ++l) {
             if (!Wx[l] || !bias[l]) return ARCVAE_ERR_ARG;
-            src[n] = Wx[l]; dst[n] = w.wt + (l - 1) * w.wsz; cols[n] = H; mode[n] = 4; ++n;
-            if (!fwd_only) { src[n] = Wx[l]; dst[n] = w.wT + (l - 1) * w.wsz; cols[n] = H; mode[n] = 5; ++n; }
+            src[n] = Wx[l]; dst[n] = w.wt + (l - 1) * w.wsz; cols[n] = H; mode[n] = b16 ? 2 : 4; ++n;
+            if (!fwd_only) { src[n] = Wx[l]; dst[n] = w.wT + (l - 1) * w.wsz; cols[n] = H; mode[n] = b16 ? 3 : 5; ++n; }
         }
         const int rc = arcvae_tile_weights(src, dst, cols, mode, n, H, stream);
         if (rc != ARCVAE_OK) return rc;
     }
+    if (b16)
+        hipLaunchKernelGGL(bf16_copies_from_f32_kernel, dim3((unsigned)((R * H + 255) / 256)), dim3(256), 0, stream, hact,
+                           reinterpret_cast<__bf16*>(w.hact_t), reinterpret_cast<__bf16*>(w.oct_h), R, H);
+    else
     hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)((R * (H >> 2) + 255) / 256)), dim3(256), 0, stream, hact,
                        reinterpret_cast<__bf16*>(w.hact_t), R, H);
     for (int l = 1; l < L; ++l) {
@@ -3487,9 +3504,10 @@ extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* c
         j.ht = w.hact_t + (long)l * w.sHt;
         j.c = w.cseq + (long)(l - 1) * R * H;
         j.gates = gates ? gates + (long)(l - 1) * R * G : nullptr;
-        j.oct = nullptr;
+        j.oct = b16 ? reinterpret_cast<__bf16*>(w.oct_h) + (long)l * R * H : nullptr;
         for (int k = 1; k < ARCVAE_MAX_LAYERS; ++k) a.job[k] = a.job[0];
-        launch_fwd_tile<4, 4, 2>(a, Ri, H, 1, stream);
+        if (b16) launch_fwd_tile<4, 4, 1>(a, Ri, H, 1, stream);
+        else launch_fwd_tile<4, 4, 2>(a, Ri, H, 1, stream);
     }
     return arcvae_launch_status();
 }
@@ -3498,14 +3516,16 @@ extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* c
 // for l = L-1 .. 1 and dh0 [R, H] = dG_1 . Wx_1 (the input of dec_l0_bwd_kernel).  dG [R, 4H]: scratch (every layer's gate
 // gradients pass through it).  `ws` as the forward left it.
 extern "C" int arcvae_dense_stack_backward(const float* gates, const float* dh_top, float* dG, float* dh0, float* const* dWx,
-                                           float* const* dbias, float* ws, long R, int H, int L, hipStream_t stream) {
+                                           float* const* dbias, float* ws, long R, int H, int L, int flags, hipStream_t stream) {
     if (!gates || !dh_top || !dG || !dh0 || !dWx || !dbias || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(dh_top) % 16) != 0) return ARCVAE_ERR_ARG;
     const int G = 4 * H, Ri = (int)R;
     const DenseWs w = dense_ws(ws, R, H, L);
+    const bool b16 = (flags & ARCVAE_LSTM_BF16) != 0;       // throughput mode: the bf16 K-split tile + the octet weight-gradient kernel
     auto launch = [&](BwdArgs& a) {
         for (int k = 1; k < ARCVAE_MAX_BWD_JOBS; ++k) a.job[k] = a.job[0];
-        hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 64 * 1024, stream, a);
+        if (b16) hipLaunchKernelGGL(lstm_bwd_tile_ks_kernel, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 48 * 1024, stream, a);
+        else hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 64 * 1024, stream, a);
     };
     for (int l = L - 1; l >= 1; --l) {
         if (!dWx[l] || !dbias[l]) return ARCVAE_ERR_ARG;
@@ -3520,8 +3540,18 @@ extern "C" int arcvae_dense_stack_backward(const float* gates, const float* dh_t
         j.gates = gates + (long)(l - 1) * R * G;
         j.c = w.cseq + (long)(l - 1) * R * H;
         j.cprev = nullptr; j.dcin = nullptr; j.dcout = w.dc;
-        j.out = dG; j.outt = w.dG_t + (l & 1) * w.sGt; j.oct = nullptr;
+        j.out = dG; j.outt = w.dG_t + (l & 1) * w.sGt; j.oct = b16 ? w.oct_g : nullptr;
         launch(a);
+        if (b16) {   // dWx_l += dG_l^T . h_{l-1} from the octet-major copies, dbias_l += colsum(dG_l)
+            const void* Ao = w.oct_g;
+            const void* Bo = reinterpret_cast<const __bf16*>(w.oct_h) + (long)(l - 1) * R * H;
+            float* Co = dWx[l];
+            int rc = arcvae_wgrad_octet_group(1, G, H, &Ri, &Ao, &Bo, &Co, H, stream);
+            if (rc) return rc;
+            rc = arcvae_colsum_accum(dG, Ri, G, G, dbias[l], 1.0f, stream);
+            if (rc) return rc;
+            continue;
+        }
         // dWx_l += dG_l^T . h_{l-1} from the planes (one time slot of R rows), dbias_l += colsum(dG_l)
         const void* Ap = w.dG_t + (l & 1) * w.sGt;
         const void* Bp = w.hact_t + (long)(l - 1) * w.sHt;

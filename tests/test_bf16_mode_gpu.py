@@ -51,6 +51,11 @@ CASES = [  # (cfg, B, T, env, forward sweep in bf16?)
     # in the precision the backward will read them in (they were always f32 -- silently wrong gradients)
     (O.Config(vocab_size=24, embedding_dim=32, hidden_dim=128, latent_dim=16, num_conditions=1, num_layers=2), 64, 8,
      {"ARCVAE_STEP_TILE": "2"}, False),
+    # the dense decoder's layers 1 .. L-1 on the bf16 tile kernels + octet weight-gradient kernel (forced; B*V a multiple of 32)
+    (O.Config(vocab_size=24, embedding_dim=16, hidden_dim=128, latent_dim=8, num_conditions=2, num_layers=3), 64, 5,
+     {"ARCVAE_STEP_TILE": "4", "ARCVAE_PERSIST": "0", "ARCVAE_DENSE_TILED": "2"}, True),
+    (O.Config(vocab_size=20, embedding_dim=16, hidden_dim=64, latent_dim=8, num_conditions=1, num_layers=2), 96, 4,
+     {"ARCVAE_STEP_TILE": "4", "ARCVAE_PERSIST": "0", "ARCVAE_DENSE_TILED": "2"}, True),
 ]
 
 
