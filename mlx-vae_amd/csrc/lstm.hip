@@ -486,7 +486,7 @@ template <int MT, int NT, int P = 0>   // P: 0 exact-f32 MFMA, 1 throughput mode
 __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_tile_kernel(FwdArgs a) {
     constexpr bool BF = P == 1, S3 = P == 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LDT = P == 2 ? 16 * NT + 4 : 16 * NT + 1;     // LDS tile row stride (three-piece form: 16-byte aligned rows for the quad epilogue)
+    constexpr int LDT = P >= 1 ? 16 * NT + 4 : 16 * NT + 1;     // LDS tile row stride (bf16 forms: 16-byte aligned rows for the quad epilogue)
     constexpr int UW = 4 * NT;           // hidden units per wave
     constexpr int NS = (MT * NT >= 16) ? 2 : 4;  // 4x4: a 4-stage ring (364 registers) measured no faster than 2
     arcvae_set_prio(a.prio);
@@ -555,8 +555,8 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
     // as the compiler knows, so a load placed after a store would wait for it, and the token -> table-row -> cell
     // chain would be paid once per pair in sequence.
     if constexpr (BF) { if (a.dbg & 2) return; }
-    if constexpr (S3) {
-        // Quad epilogue (round 3): a lane owns FOUR ADJACENT units of a row -- their 16 pre-activations are 64 contiguous bytes of
+    if constexpr (S3 || BF) {
+        // Quad epilogue (round 3; both bf16 forms): a lane owns FOUR ADJACENT units of a row -- their 16 pre-activations are 64 contiguous bytes of
         // the LDS tile (the permuted gate columns: 4 units x (i, f, g, o)), and every global access is 16 bytes per lane (8 for a
         // bf16 plane): 14 memory instructions per four (row, unit) pairs instead of per pair.  16 MT NT quads per wave.
         constexpr int NQ = 16 * MT * NT, QPL = (NQ + 63) / 64;
@@ -610,10 +610,20 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
                 *reinterpret_cast<f32x4*>(j.c + hb) = cc;
             }
             if (a.lite & 2) continue;
+            __bf16* hp = reinterpret_cast<__bf16*>(j.ht) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
+            if constexpr (BF) {   // throughput mode: one plane + the octet-major copy of the weight-gradient kernel
+                const bf16x4_l b4 = bf16x4_l{to_bf16(hv[0]), to_bf16(hv[1]), to_bf16(hv[2]), to_bf16(hv[3])};
+                *reinterpret_cast<bf16x4_l*>(hp) = b4;
+                if (j.oct) {
+                    __bf16* op = reinterpret_cast<__bf16*>(j.oct) + ((long)(row >> 3) * H + unit) * 8 + (row & 7);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) op[k * 8] = b4[k];
+                }
+                continue;
+            }
             __bf16 pc[3][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) split3_bf16(hv[k], pc[0][k], pc[1][k], pc[2][k]);
-            __bf16* hp = reinterpret_cast<__bf16*>(j.ht) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
             const long pl = (long)B * H;
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz)
@@ -942,6 +952,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_ks_kernel(BwdArgs a) {
 #ifndef ARCVAE_KS3_PIN
 #define ARCVAE_KS3_PIN 1
 #endif
+template <int P = 2>   // P = 2: three bf16 pieces (parity path); P = 1: throughput mode (one bf16 plane + the octet-major copy)
 __global__ __launch_bounds__(256) void lstm_bwd_tile_ks3_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ksred[];     // [4 dst groups][4 src waves][4 n][4 regs][64 lanes]
     arcvae_set_prio(a.prio);
@@ -974,11 +985,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_ks3_kernel(BwdArgs a) {
         const int nq = G >> 7;                            // 32-wide chunks per wave (G / 32 / 4)
         const __bf16* At = reinterpret_cast<const __bf16*>(j.src) + (long)wave * nq * B * 32;
         const __bf16* Wt = reinterpret_cast<const __bf16*>(j.WT) + (long)wave * nq * H * 32;
+        if constexpr (P == 1) {
+            tile_contract_b<4, 4, 4>(acc, At, arow, B, Wt, wrow, H, nq, (lane >> 4) * 8);
+        } else {
 #if ARCVAE_S3_RING2_KS
         tile_contract_s2<4, 4>(acc, At, (long)B * G, arow, B, Wt, (long)H * G, wrow, H, nq, (lane >> 4) * 8);
 #else
         tile_contract_s<4, 4, 2>(acc, At, (long)B * G, arow, B, Wt, (long)H * G, wrow, H, nq, (lane >> 4) * 8);
 #endif
+        }
         // every partial tile through LDS: group m of wave w -> slot [m][w]; element (n, reg) of lane = row 16 m + 4 (lane >> 4) + reg,
         // unit u0 + 16 n + (lane & 15)
 #pragma unroll
@@ -1056,16 +1071,28 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_ks3_kernel(BwdArgs a) {
             __bf16* tp = reinterpret_cast<__bf16*>(j.outt) + ((long)(unit >> 5) * B + row) * 32 + (unit & 31);
             const long gs = (long)(H >> 5) * B * 32, pl = (long)B * G;
             const f32x4 dv[4] = {d_i, d_f, d_g, d_o};
+            typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+            if constexpr (P == 1) {   // throughput mode: one plane (8 bytes per gate) + the octet-major copy of the weight-gradient kernel
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x4_l b4 = bf16x4_l{to_bf16(dv[q][0]), to_bf16(dv[q][1]), to_bf16(dv[q][2]), to_bf16(dv[q][3])};
+                    *reinterpret_cast<bf16x4_l*>(tp + q * gs) = b4;
+                    if (j.oct) {
+                        __bf16* op = reinterpret_cast<__bf16*>(j.oct) + ((long)(row >> 3) * G + q * H + unit) * 8 + (row & 7);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) op[k * 8] = b4[k];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 __bf16 pc[3][4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) split3_bf16(dv[q][k], pc[0][k], pc[1][k], pc[2][k]);
 #pragma unroll
-                for (int pz = 0; pz < 3; ++pz) {
-                    typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+                for (int pz = 0; pz < 3; ++pz)
                     *reinterpret_cast<bf16x4_l*>(tp + q * gs + pz * pl) = bf16x4_l{pc[pz][0], pc[pz][1], pc[pz][2], pc[pz][3]};
-                }
+            }
             }
         }
     }
@@ -1089,7 +1116,7 @@ inline int choose_tile_mt(int B, int col_blocks, int jobs, int minb = 200) {
 template <int MT, int NT, int P = 0>
 void launch_fwd_tile(const FwdArgs& a, int B, int H, int nj, hipStream_t s) {
     dim3 grid(H / (16 * NT), ceil_div(B, 16 * MT), nj);
-    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT, P>), grid, dim3(256), 4 * 16 * MT * (16 * NT + (P == 2 ? 4 : 1)) * sizeof(float), s, a);
+    hipLaunchKernelGGL((lstm_fwd_tile_kernel<MT, NT, P>), grid, dim3(256), 4 * 16 * MT * (16 * NT + (P >= 1 ? 4 : 1)) * sizeof(float), s, a);
 }
 template <int MT, int P = 0>
 void launch_bwd_tile(const BwdArgs& a, dim3 grid, hipStream_t s) {
@@ -3347,6 +3374,11 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
             dim3 tgrid(ceil_div(H, 128), ceil_div(B, 16 * tile_mt), nj);
             // ARCVAE_BWD_KSPLIT (default 1): the K-split 64 x 64 form where its grid fills the chip
             if (b16 && tile_mt == 4 && arcvae_env_int("ARCVAE_BWD_KSPLIT", 1) != 0 && (H / 64) * ceil_div(B, 64) * nj >= 200) {
+                // (ARCVAE_BF16_KS_QUAD, default 1: the K-split tile with the four-unit epilogue of the three-piece form; 0: the
+                // round-2 kernel with one (row, unit) per lane and element)
+                if (arcvae_env_int("ARCVAE_BF16_KS_QUAD", 1) != 0 && (ld_dh_top % 4) == 0 && (reinterpret_cast<uintptr_t>(dh_top) % 16) == 0)
+                    hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel<1>, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 64 * 1024, stream, a);
+                else
                 hipLaunchKernelGGL(lstm_bwd_tile_ks_kernel, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 48 * 1024, stream, a);
                 continue;
             }
@@ -3356,7 +3388,7 @@ extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* con
                 const int ks3 = arcvae_env_int("ARCVAE_BWD_KSPLIT3", 1);   // (read per call: tests toggle it)
                 if (ks3 != 0 && (ks3 == 2 || (H / 64) * ceil_div(B, 64) * nj >= tile_min_blocks(flags)) && (ld_dh_top % 4) == 0 &&
                     (reinterpret_cast<uintptr_t>(dh_top) % 16) == 0) {
-                    hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 64 * 1024, stream, a);
+                    hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel<2>, dim3(H / 64, ceil_div(B, 64), nj), dim3(256), 64 * 1024, stream, a);
                     continue;
                 }
                 if (tile_mt == 4) launch_bwd_tile<4, 2>(a, tgrid, stream);
@@ -3524,8 +3556,8 @@ extern "C" int arcvae_dense_stack_backward(const float* gates, const float* dh_t
     const bool b16 = (flags & ARCVAE_LSTM_BF16) != 0;       // throughput mode: the bf16 K-split tile + the octet weight-gradient kernel
     auto launch = [&](BwdArgs& a) {
         for (int k = 1; k < ARCVAE_MAX_BWD_JOBS; ++k) a.job[k] = a.job[0];
-        if (b16) hipLaunchKernelGGL(lstm_bwd_tile_ks_kernel, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 48 * 1024, stream, a);
-        else hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 64 * 1024, stream, a);
+        if (b16) hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel<1>, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 64 * 1024, stream, a);
+        else hipLaunchKernelGGL(lstm_bwd_tile_ks3_kernel<2>, dim3(H / 64, ceil_div(Ri, 64), 1), dim3(256), 64 * 1024, stream, a);
     };
     for (int l = L - 1; l >= 1; --l) {
         if (!dWx[l] || !dbias[l]) return ARCVAE_ERR_ARG;
