@@ -789,6 +789,8 @@ def roofline_probe(eng, ws, torch):
     if pmc:
         try:
             ent = json.load(open(pmc)).get(kernel.split(" / ")[0], {})   # (a family is looked up by its first, dominant member)
+            if "shape" in ent and list(ent["shape"]) != [B, d.H, d.L]:
+                ent = {}     # (counters of this kernel were taken at another shape [B, H, L]: no figure for this leg)
             traffic = ent.get("bytes_per_tick", ent.get("bytes_per_launch"))
             traffic_source = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc, separate passes; not measured in this run)"
         except Exception:
