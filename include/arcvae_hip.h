@@ -54,8 +54,14 @@ extern "C" {
                                    * v_mfma_f32_16x16x32_bf16 products where the shape runs on the register-tiled step kernels
                                    * (the MFMA-bound regime, e.g. H512 L4 bs 512); gates, cell state and accumulators stay f32.
                                    * The k-chunk-major workspaces (hseq_t, dG_t, wt, wT) then hold bf16 in 32-wide chunks --
-                                   * same pointers, half the bytes, so buffers sized for f32 are always large enough; forward
-                                   * and backward of a step must be given the same flag */
+                                   * same pointers, half the bytes; forward and backward of a step must be given the same flag */
+#define ARCVAE_LSTM_SPLIT3 4      /* arcvae_enc_lstm_forward / _backward flags bit 2 (what the engine passes on the PARITY path): where the
+                                   * shape runs on the register-tiled step kernels every operand value is three bf16 pieces (hi + mid
+                                   * + lo, 8 + 8 + 8 bits), six products on v_mfma_f32_16x16x32_bf16, f32 accumulate -- the accuracy
+                                   * class of the exact-f32 kernels.  The operand workspaces (hseq_t, dG_t, wt, wT) then hold THREE
+                                   * bf16 planes per value: 6 bytes instead of 4, i.e. 3/2 of the f32 sizes, and where the weight
+                                   * gradients read those planes the rings keep all T time slots: size them with
+                                   * arcvae_enc_lstm_ws_floats and pass the capacities to every call (ws_floats) */
 #define ARCVAE_PERSIST_BF16 2     /* arcvae_enc_lstm_forward_persistent flags bit 1 / arcvae_enc_lstm_backward_persistent_rs flags
                                    * bit 1: throughput mode for the persistent sweeps -- the 4x4 MFMA blocks (H 256, B <= 64
                                    * forward, B <= 128 BPTT) on v_mfma_f32_4x4x4_16b_bf16, weights and h / dG rounded to bf16
@@ -72,7 +78,14 @@ extern "C" {
 #define ARCVAE_DEC_BF16 256       /* arcvae_dec_forward_dense `mode` bit 8 / arcvae_dec_backward_dense `flags` bit 8: the B*V-row
                                    * products with ARCVAE_GEMM_BF16 */
 
-typedef void* arcvae_stream_t; /* hipStream_t */
+/* A hipStream_t.  Callers without the HIP headers pass it as void*; the library's own translation units include this header
+ * too (csrc/common.h defines ARCVAE_HIP_BUILD behind <hip/hip_runtime.h>), so a declaration here that drifts from its
+ * definition in csrc/ is a compile error ("conflicting declaration of C function"), not a silent ABI mismatch. */
+#ifdef ARCVAE_HIP_BUILD
+typedef hipStream_t arcvae_stream_t;
+#else
+typedef void* arcvae_stream_t;
+#endif
 
 /* ABI version / build probe: returns 1000*major + minor; *arch_gfx950 = 1 when the code object
  * was built for gfx950. */
@@ -92,13 +105,21 @@ int arcvae_gemm_f32(int transA, int transB, int M, int N, int K, const float* A,
  * x_tb [T,B] int32 tokens (time-major; arcvae_transpose_tokens makes it from [B,T]);
  * table0 [V,4H] = embedding . Wx_0^T + bias_0 (one arcvae_gemm_f32 call);
  * outputs hseq,cseq [L,T,B,H], gseq [L,T,B,4H] (post-activation gates, saved for BPTT);
- * workspaces hseq_t [L,RS,B*H] (ring over t, RS = min(T,16) slots; a [L,T,B*H] buffer is always large enough) and wt [(2L-1),4H*H]: k-chunk-major operand copies for the
- * step kernels. */
+ * workspaces: hseq_t [L, slots, B*H*q] -- the k-chunk-major operand copy of h_t in ring slot t % slots -- and wt [(2L-1), 4H*H*q],
+ * the k-chunk-major weight copies, where q = 3/2 in the three-piece form (ARCVAE_LSTM_SPLIT3 where the shape runs on the tile
+ * kernels: three bf16 planes per value) and 1 otherwise, and slots = arcvae_enc_lstm_operand_slots(B, T, H, L, flags): min(T, 16),
+ * or T where the weight gradients read the operand planes.  The library decides q and slots from (B, H, L, flags) and the
+ * ARCVAE_* kernel-family knobs at EVERY call, so the caller states what it allocated: ws_floats[4] = capacities in floats of
+ * {hseq_t, dG_t, wt, wT} (HOST array; entries of buffers a call does not use are ignored).  A call whose kernel family needs more
+ * than that returns ARCVAE_ERR_ARG before launching anything -- never a write past the buffer.  arcvae_enc_lstm_ws_floats
+ * returns the sizes needed under the current knobs. */
+int arcvae_enc_lstm_ws_floats(int B, int T, int H, int L, int flags, long* floats /* out [4]: hseq_t, dG_t, wt, wT */);
 int arcvae_transpose_tokens(const int32_t* src_bt, int32_t* dst_tb, int B, int T, arcvae_stream_t stream);
 int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                             const float* const* Wh, const float* const* bias, float* hseq, float* hseq_t,
                             float* cseq, float* gseq, float* wt, float* wT_bwd /* optional */, int B, int T, int V,
-                            int H, int L, int flags /* ARCVAE_LSTM_BF16 or 0; the same value must go to the backward */,
+                            int H, int L, int flags /* ARCVAE_LSTM_SPLIT3, ARCVAE_LSTM_BF16 or 0; the same value must go to the
+                            backward */, const long* ws_floats /* [4] capacities: hseq_t, -, wt, wT_bwd */,
                             void* h_oct /* optional, throughput mode: [L,T*B/8,H,8] bf16 "octet-major" copy of hseq
                             (k = t*B + b in groups of 8 per row: the layout an MFMA fragment is loaded in) for
                             arcvae_enc_lstm_wgrad; written when the tiled bf16 kernels run and B % 16 == 0 */,
@@ -116,12 +137,14 @@ int arcvae_enc_lstm_tiled_for(int B, int H, int L, int flags);
 int arcvae_enc_lstm_operand_slots(int B, int T, int H, int L, int flags);
 /* Backward of the above (the part of mx.value_and_grad, trainer.py:292, that walks the encoder
  * LSTM graph).  dh_top [B, ld_dh_top]: gradient w.r.t. the top layer's h at t = T-1, the only
- * position read by models/encoder.py:106.  dG out [L,T,B,4H] (may alias gseq: in-place); dG_t ws [L,RS,B*4H]; dcs, dxs
- * ws [L,RS,B,H] (rings over t with RS = min(T,16) slots: a slab is consumed by the next launch only); wT ws [(2L-1),H*4H]. */
+ * position read by models/encoder.py:106.  dG out [L,T,B,4H] (may alias gseq: in-place); dG_t ws [L,slots,B*4H*q] and wT ws
+ * [(2L-1),H*4H*q] with slots and q as for the forward (capacities in ws_floats[1] and [3]); dcs, dxs ws [L,RS,B,H], rings over t
+ * with RS = min(T,16) slots (ARCVAE_RING) whatever the form: a slab is consumed by the next launch only. */
 int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                              const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dG_t,
                              float* dcs, float* dxs, float* wT, int B, int T, int H, int L, int s_begin,
-                             int s_end, int flags /* ARCVAE_LSTM_RETILE | ARCVAE_LSTM_BF16 */,
+                             int s_end, int flags /* ARCVAE_LSTM_RETILE | ARCVAE_LSTM_SPLIT3 or ARCVAE_LSTM_BF16 */,
+                             const long* ws_floats /* [4] capacities: -, dG_t, -, wT */,
                              void* dG_oct /* optional, throughput mode: [L,T*B/8,4H,8] bf16 octet-major copy of dG */,
                              unsigned* start_signal /* optional: += 1 when the first launch of
                              this call starts (all earlier work of the stream is complete) */,
@@ -144,7 +167,8 @@ int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L);
  * re-armed by arcvae_enc_prologue; bit 1: ARCVAE_PERSIST_BF16.) */
 int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq, float* cseq,
-                                       float* gseq, float* wT_bwd, float* comb /* optional [B,2H]: its first H columns
+                                       float* gseq, float* wT_bwd, long wT_bwd_floats /* capacity of wT_bwd in floats (entry [3] of
+                                       arcvae_enc_lstm_ws_floats); ignored when wT_bwd is NULL */, float* comb /* optional [B,2H]: its first H columns
                                        receive h_{T-1} of the top layer, the heads' input (models/encoder.py:106) */,
                                        unsigned* sync_ws, unsigned* start_signal, int B, int T, int V, int H, int L,
                                        int flags, unsigned long long* trace, arcvae_stream_t stream);
@@ -170,6 +194,9 @@ int arcvae_enc_lstm_backward_persistent(const float* cseq, const float* gseq, co
  * reduce-scattered through the XCD's L2 (part_ws: RG*2*(2L-1)*8*32*32*64 floats, RG = 1 / 2 / 4 groups of 8 rows per
  * XCD for B <= 64 / 128 / 256).  Otherwise as arcvae_enc_lstm_backward_persistent. */
 int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
+/* Floats of part_ws that sweep uses for this shape under the current knobs (0 where it does not run): pass the capacity the
+ * caller allocated as part_ws_floats -- a call that would need more returns ARCVAE_ERR_ARG. */
+long arcvae_enc_lstm_bwd_rs_part_floats(int B, int T, int H, int L);
 /* 2 where the persistent sweeps run in their TWO-GROUP form (H = 256, L <= 2, 129 <= B <= 256: the 256-row shard of
  * BASELINE.json configs[3]), else 1.  Two groups: 512 blocks, two per CU; every XCD's 17..32 rows are two independent
  * recurrences of up to 16 rows with their own flag lines, and a CU's two blocks serve different groups, so that one group's
@@ -179,8 +206,8 @@ int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
 int arcvae_enc_lstm_persist_groups(int B, int H, int L);
 int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
                                            const float* gseq, const float* dh_top, int ld_dh_top, float* dG, float* dcs,
-                                           float* dxs, float* part_ws, unsigned* sync_ws, unsigned* start_signal, int B,
-                                           int T, int H, int L, int s_begin, int s_end, int chunk_index,
+                                           float* dxs, float* part_ws, long part_ws_floats, unsigned* sync_ws,
+                                           unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end, int chunk_index,
                                            int flags /* bit 0: sync_ws was re-armed ahead of the step (arcvae_enc_prologue with
                                            n_sync >= 848); bit 1: ARCVAE_PERSIST_BF16 */, unsigned long long* trace,
                                            arcvae_stream_t stream);
@@ -191,7 +218,7 @@ int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* 
  * written / read by the forward sweep; dWx, dWh, dbias: HOST arrays of device pointers.  Same shape rule as _rs. */
 int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* Wh, const float* cseq, const float* gseq,
                                    const float* hseq, const int32_t* x_tb, const float* dh_top, int ld_dh_top,
-                                   float* dG, float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
+                                   float* dG, float* dcs, float* dxs, float* part_ws, long part_ws_floats, unsigned* sync_ws,
                                    unsigned* start_signal, float* const* dWx, float* const* dWh, float* const* dbias,
                                    float* dtable_ws, int B, int T, int V, int H, int L, int s_begin, int s_end,
                                    int chunk_index, unsigned long long* trace, arcvae_stream_t stream);
@@ -217,7 +244,9 @@ int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, const float* Wx
                           int t_lo, int t_hi, int first, int last, int parts /* 1 layers | 2 token table */,
                           const void* h_oct, const void* dG_oct /* optional (both or none), with parts bit 7: the octet-major
                           bf16 copies the sweeps of this step wrote -- the per-layer GEMMs then read those */,
-                          arcvae_stream_t stream);
+                          const long* ws_floats /* with parts bit 11 (h_oct / dG_oct are plane rings with all T slots: [L,T,B*H*3/2]
+                          and [L,T,B*4H*3/2] floats): [0], [1] = their capacities in floats, checked -- ARCVAE_ERR_ARG when smaller;
+                          may be NULL otherwise */, arcvae_stream_t stream);
 
 /* ---- encoder heads + reparameterisation + latent loss ----------------------------------------
  * models/encoder.py:106-130 (condition_fc, fc_mu, fc_logvar_hidden, fc_logvar, tanh bounds),
@@ -310,12 +339,13 @@ int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const fl
  *   (HOST arrays [L], entry 0 unused), `ws` as the forward left it. */
 int arcvae_dense_stack_ok(long R, int H, int L);
 int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats /* out */);
-int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws, long R,
+int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws,
+                               long ws_floats /* capacity of ws in floats: >= arcvae_dense_stack_ws_floats, else ARCVAE_ERR_ARG */, long R,
                                int H, int L, int flags /* bit 0: forward only (sampler): nothing the backward needs is written;
                                ARCVAE_LSTM_BF16 (bit 1): throughput mode -- bf16 operand copies, one product (not a parity path) */,
                                arcvae_stream_t stream);
 int arcvae_dense_stack_backward(const float* gates, const float* dh_top, float* dG, float* dh0, float* const* dWx,
-                                float* const* dbias, float* ws, long R, int H, int L, int flags /* ARCVAE_LSTM_BF16 or 0: as the
+                                float* const* dbias, float* ws, long ws_floats, long R, int H, int L, int flags /* ARCVAE_LSTM_BF16 or 0: as the
                                 forward was called */, arcvae_stream_t stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------------

@@ -45,26 +45,28 @@ SIGNATURES = {
     "arcvae_abi_version": [_ip],
     "arcvae_gemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp],
     "arcvae_transpose_tokens": [_vp, _vp, _i, _i, _vp],
-    "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "arcvae_enc_lstm_ws_floats": [_i, _i, _i, _i, _i, _lp],
+    "arcvae_enc_lstm_forward": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _lp, _vp, _vp, _vp],
     "arcvae_enc_lstm_tiled": [_i, _i, _i],
     "arcvae_enc_lstm_tiled_for": [_i, _i, _i, _i],
     "arcvae_enc_lstm_operand_slots": [_i, _i, _i, _i, _i],
     "arcvae_dense_stack_ok": [_l, _i, _i],
     "arcvae_dense_stack_ws_floats": [_l, _i, _i, _lp],
-    "arcvae_dense_stack_forward": [_pp, _pp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
-    "arcvae_dense_stack_backward": [_vp, _vp, _vp, _vp, _pp, _pp, _vp, _l, _i, _i, _i, _vp],
+    "arcvae_dense_stack_forward": [_pp, _pp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp],
+    "arcvae_dense_stack_backward": [_vp, _vp, _vp, _vp, _pp, _pp, _vp, _l, _l, _i, _i, _i, _vp],
     "arcvae_enc_lstm_persistent_ok": [_i, _i, _i, _i],
-    "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_lstm_forward_persistent": [_vp, _vp, _pp, _pp, _pp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_prologue": [_vp, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "arcvae_enc_lstm_bwd_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_rs_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_persist_groups": [_i, _i, _i],
-    "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "arcvae_enc_lstm_backward_fused": [_pp, _pp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _vp,
+    "arcvae_enc_lstm_bwd_rs_part_floats": [_i, _i, _i, _i],
+    "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "arcvae_enc_lstm_backward_fused": [_pp, _pp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _pp, _pp, _pp, _vp,
                                        _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _lp, _vp, _vp, _vp, _vp],
+    "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _lp, _vp],
     "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _i, _vp],
     "arcvae_stats_set_recon": [_vp, _i, _vp, _i, _vp],
     "arcvae_latent_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
@@ -97,6 +99,8 @@ SIGNATURES = {
     "arcvae_copy_buffers": [_pp, _pp, _lp, _i, _vp],
 }
 
+LONG_RESULTS = {"arcvae_enc_lstm_bwd_rs_part_floats"}      # size queries returning `long`; everything else returns an int code
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -117,7 +121,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_long if name in LONG_RESULTS else C.c_int
     _lib = lib
     return lib
 

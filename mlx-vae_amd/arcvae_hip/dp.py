@@ -12,8 +12,10 @@ step needs exactly two exchanges:
                     "overlapped with the backward LSTM sweep"): the decoder's share [dec.grad | CE sum]
                     (3.9 MB) is complete ~0.6 ms before the encoder's -- the decoder never reads z (Q2) -- and
                     is reduced on the SIDE stream right behind the decoder's backward, through a SECOND
-                    communicator, i.e. beside the BPTT sweep; the encoder's share (5.3 MB) is reduced on
-                    the main stream after the sweep's last weight-gradient chunk.  Messages are <= 5.3 MB:
+                    communicator, i.e. beside the BPTT sweep; the encoder HEADS' share (1.58 MB: condition_fc, fc_mu,
+                    fc_logvar_hidden, fc_logvar -- complete right behind the stats seam, before the BPTT has moved) follows
+                    it on the same stream and communicator (round 4); what stays exposed on the main stream after the
+                    sweep's last weight-gradient chunk is the LSTM layers + embedding (3.7 MB).  Messages are <= 3.9 MB:
                     on point-to-point xGMI RCCL picks a direct reduce-scatter/all-gather rather than a
                     per-link-bound ring.
 
@@ -48,6 +50,10 @@ class StepOps(Protocol):
     def early_context(self) -> ContextManager: ...      # stream context the early reduces are issued from
     def recon_local(self) -> None: ...        # fills the CE sum (inside early_context)
     def early_done(self) -> None: ...         # optional: early buckets are GLOBAL (inside early_context)
+    def seam_buckets(self) -> List[torch.Tensor]: ...   # optional: gradients complete right behind the stats seam (the encoder
+    #                                             heads'): reduced on the EARLY communicator, behind the early buckets
+    seam_issue_early: bool                    # optional: True = the ops order them on the device (a gate on the early stream), so
+    #                                             they are ISSUED with the early buckets, ahead of backward_local's enqueue
     def apply_update(self) -> None: ...       # the CE sum is GLOBAL by now
 
 
@@ -62,7 +68,7 @@ class DataParallelStep:
         early (decoder) bucket -- a SECOND one, because those reduces are issued from another stream and run
         concurrently with the first group's; created here (collectively: every rank constructs its driver) when not
         given.  Per communicator the issue order is the same on every rank: {stats, late buckets} and {CE sum, early
-        buckets}."""
+        buckets, seam buckets}."""
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -85,6 +91,8 @@ class DataParallelStep:
 
     def step(self) -> None:
         ops = self.ops
+        seam = getattr(ops, "seam_buckets", None)
+        seam_early = seam is not None and bool(getattr(ops, "seam_issue_early", False))
         ops.forward_local()
         with ops.early_context():                       # decoder-side results: independent of the stats seam (Q2), so
             ops.recon_local()                           # issued first -- they run beside the encoder's sweeps
@@ -94,8 +102,15 @@ class DataParallelStep:
             done = getattr(ops, "early_done", None)
             if done is not None:
                 done()
+            if seam_early:                              # the encoder heads' gradients: ready right behind the seam; the ops
+                for g in seam():                        # put a device-side gate in front of the reduce (SURVEY 8e bucket order)
+                    self._all_reduce(g, self.early_group)
         self._all_reduce(ops.stats)                     # forward seam (critical path, 2Z+3 floats)
         ops.backward_local()
+        if seam is not None and not seam_early:         # host-ordered forms (CPU doubles, event form): behind the backward
+            with ops.early_context():
+                for g in seam():
+                    self._all_reduce(g, self.early_group)
         for g in ops.late_buckets():
             self._all_reduce(g)
         ops.apply_update()
@@ -108,22 +123,31 @@ class EngineOps:
       main stream : signal -> [enc_fwd] -> (all-reduce stats) -> [loss + dcomb + sweep chunks + signals]
                     -> join aux, side -> (all-reduce enc.grad) -> [finalize + encoder adam]
       side stream : gate -> [dec_fwd + dec_bwd] -> [CE sum] -> (all-reduce dec.grad | CE sum, SECOND communicator)
-                    -> [decoder adam] ... gate -> [weight-gradient pieces of the sweep chunks]
+                    -> [decoder adam] -> gate "heads' gradients formed" -> (all-reduce the encoder heads' gradients, same
+                    communicator) ... gate -> [weight-gradient pieces of the sweep chunks]
       aux stream  : gate -> [weight gradients of chunk c] ...
       The gradient bucket is one contiguous buffer (the stores' `grad` tensors are re-pointed into it) reduced in
       two pieces: the decoder's 3.9 MB in SIDE's stream order right behind the decoder's backward -- no event, no
       gate: the collective is just the next operation of that stream, so nothing sits blocked beside the chain --
       which puts it beside the encoder's forward / BPTT sweeps (north_star: "overlapped with the backward LSTM
-      sweep"); the encoder's 5.3 MB on main after the join.  Two communicators, each used from exactly one stream
-      with the same issue order on every rank ({stats, enc.grad} on main's, {dec bucket} on side's).
+      sweep"); behind it, on the same stream and communicator, the encoder HEADS' 1.58 MB (the tail of enc.grad: complete
+      once aux has run heads_wgrad right behind the seam -- gate word HG); the LSTM layers' + embedding's 3.7 MB on main
+      after the join (SURVEY 8e's bucket order; ARCVAE_DP_HEADS_EARLY=0: the whole 5.3 MB after the join, as in round 3).
+      Two communicators, each used from exactly one stream with the same issue order on every rank ({stats, enc LSTM
+      bucket} on main's, {dec bucket, heads bucket} on side's).
 
     Event form (fallback when the gate probe fails, ARCVAE_GATES=0): as in round 1 --
       side: [dec_fwd] -> ev_chain -> [dec_bwd] -> ev_dec_bwd;  comm stream: CE sum and dec.grad reduced beside the
       BPTT sweep;  enc.grad reduced after it.
     """
 
-    def __init__(self, engine, ws, lr: float, global_rows: int, use_graph: bool = True):
+    def __init__(self, engine, ws, lr: float, global_rows: int, use_graph: bool = True,
+                 group: Optional[dist.ProcessGroup] = None):
+        """group: the communicator of the DataParallelStep this ops object will be driven by (None = the default group).  The
+        two collectives issued HERE -- the warm-up and the agreement on the gated / event form -- run on it: with a subgroup,
+        ranks outside it never construct an EngineOps, and a collective on the default group would hang."""
         self.eng, self.ws, self.lr = engine, ws, float(lr)
+        self.group = group
         self.global_rows = int(global_rows)
         Z = engine.d.Z
         self.stats = ws.stats[:2 * Z + 3]
@@ -132,20 +156,19 @@ class EngineOps:
             # warm the communicator up (channel / IPC set-up of the first collective can take seconds on 8 GPUs) before
             # any gate kernel can be left spinning behind it
             warm = torch.zeros(1024, dtype=torch.float32, device=engine.device)
-            dist.all_reduce(warm)
+            dist.all_reduce(warm, group=group)
             torch.cuda.synchronize()
         self.gated = engine.mode != "graph" and engine._gating_ok(torch.cuda.current_stream())
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            # the two forms issue different collective sequences: every rank must take the same one
-            flag = torch.tensor([1.0 if self.gated else 0.0], device=engine.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            self.gated = bool(flag.item() > 0.5)
+        self.gated = agree_all(self.gated, group, engine.device)
         # ARCVAE_DP_EARLY_REDUCE=0: round 1's ordering -- nothing is reduced beside the sweeps: the whole bucket [enc.grad |
         # dec.grad | CE sum] is ONE all-reduce on main after the join, and the decoder's Adam update moves into the finish
         # segment.  The default (early decoder reduce on side, second communicator) is UNMEASURED on more than one GPU: an RCCL
         # kernel that waits for a slower peer holds CU resources beside persistent sweeps that need a resident block on
         # every CU; this switch is the fallback if that turns out to cost more than the overlap gains.
         self.early = os.environ.get("ARCVAE_DP_EARLY_REDUCE", "1") != "0"
+        # the encoder heads' gradients reduced early as well (gated + early form only): SURVEY 8e's second bucket
+        self.heads_early = self.gated and self.early and os.environ.get("ARCVAE_DP_HEADS_EARLY", "1") != "0"
+        self.seam_issue_early = True     # (DataParallelStep: seam buckets are ordered by a device-side gate, issue them on side now)
         if self.gated:
             self._make_bucket()
             self.recon_stat = None
@@ -179,7 +202,10 @@ class EngineOps:
             eng._graphs.clear()
             self.run = eng.runner(self.ws, self.lr, self.global_rows, capture=self.run.capture)
         self.bucket = cur
+        nh = eng.enc.offsets["condition_fc.weight"]   # the heads' parameters are the tail of the encoder's flat buffer (store.py)
         self.bucket_enc = cur[:ne]               # complete after the join (last weight-gradient chunk)
+        self.bucket_enc_lstm = cur[:nh]          # embedding + LSTM layers: what stays exposed behind the sweep
+        self.bucket_heads = cur[nh:ne]           # condition_fc, fc_mu, fc_logvar_hidden, fc_logvar: complete right behind the seam
         self.bucket_dec = cur[ne:ne + nd + 64]   # decoder gradients + CE sum: complete long before the sweep ends
         self.bucket_recon = cur[ne + nd:ne + nd + 1]
 
@@ -271,10 +297,25 @@ class EngineOps:
         if self.gated and self.early:
             self._dec_adam_gated()                   # decoder gradients are GLOBAL: its Adam update rides on side too
 
+    def seam_buckets(self) -> List[torch.Tensor]:
+        """The encoder heads' gradients, on SIDE behind the decoder's bucket: a device-side gate (word HG, raised by aux once
+        heads_wgrad of THIS step has run: engine._encoder_backward_gated) orders the reduce behind them."""
+        if not self.heads_early:
+            return []
+        from .engine import EncoderBackwardPlan
+        g = self.eng.gates
+        # side's ticket counter NS is advanced by the LAST gate of a step on side: with a single-chunk sweep that is the decoder
+        # segment's own gate (in front of this one: offset 0), else the tail chunk's (behind it: offset 1)
+        off = 0 if len(EncoderBackwardPlan(self.eng.enc, self.ws, self.eng.d).chunks) < 2 else 1
+        self.run("dp_heads_gate", lambda: g.wait(g.HG, g.NS, 1, off), torch.cuda.current_stream())
+        return [self.bucket_heads]
+
     def late_buckets(self) -> List[torch.Tensor]:
         if self.gated:
-            self._join_gated()
-            return [self.bucket_enc] if self.early else [self.bucket]   # (late form: side wrote its half before the join)
+            self._join_gated()       # (R: aux's and side's last pieces -- side's follows the heads' reduce in stream order)
+            if not self.early:
+                return [self.bucket]                      # (late form: side wrote its half before the join)
+            return [self.bucket_enc_lstm] if self.heads_early else [self.bucket_enc]
         return [self.eng.enc.grad]
 
     def apply_update(self) -> None:
@@ -283,6 +324,16 @@ class EngineOps:
             return
         torch.cuda.current_stream().wait_stream(self.comm)
         self.eng.enqueue_finish(self.ws, self.lr, True, self.run)
+
+
+def agree_all(flag: bool, group: Optional[dist.ProcessGroup], device) -> bool:
+    """True iff `flag` holds on EVERY rank of `group` (MIN all-reduce on that group -- never on the default group when a
+    subgroup drives the step); the plain value without a process group or at world size 1."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() > 0.5)
 
 
 # ---- the trainer's two calls under data parallelism ------------------------------------------------------------------
@@ -355,7 +406,7 @@ class EngineDataParallel:
         key = (hi - lo, T, n, float(lr), float(eng.hyper_host["free_bits"]))
         drv = self._drivers.get(key)
         if drv is None:
-            ops = EngineOps(eng, ws, lr, n, use_graph=(eng.mode != "eager"))
+            ops = EngineOps(eng, ws, lr, n, use_graph=(eng.mode != "eager"), group=self.group)
             drv = DataParallelStep(ops, self.group, early_group=self._early_group)
             self._early_group = drv.early_group
             self._drivers[key] = drv

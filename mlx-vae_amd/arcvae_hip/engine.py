@@ -135,9 +135,9 @@ class Workspace:
             self.dtable1 = self.dtables[1]                    # the last chunk's token table, folded by the main stream itself
             self.tables_zeroed = False                        # this step's prologue has zeroed them (persistent forward path)
             self.onehot = torch.empty(T * B, (V + 3) // 4 * 4, **f32)   # one-hot token rows (token-table gradient)
-            if _lib.load().arcvae_enc_lstm_bwd_rs_ok(B, T, H, L) == 1:   # partial sums in flight of the reduce-scatter BPTT sweep
-                rg = 1 if B <= 64 else (2 if B <= 128 else 4)   # (12.6 MB per group of 8 rows per XCD; only where that sweep runs)
-                self.ppart = torch.empty(rg * 2 * (2 * L - 1) * 8 * 32 * 32 * 64, **f32)
+            npart = _lib.load().arcvae_enc_lstm_bwd_rs_part_floats(B, T, H, L)   # partial sums in flight of the reduce-scatter BPTT sweep
+            if npart > 0:                                   # (12.6 MB per group of 8 rows per XCD; the size is the library's to say)
+                self.ppart = torch.empty(npart, **f32)
             self.dlogits = torch.empty(BV, V, **f32)
             self.ddh = torch.empty(2, BV, H, **f32)
             self.ddG = torch.empty(BV, G, **f32)
@@ -152,6 +152,17 @@ def _lstm_flags(ws) -> int:
     if ws.bf16_parts & 1:
         return _lib.LSTM_BF16
     return _lib.LSTM_SPLIT3 if os.environ.get("ARCVAE_LSTM_SPLIT3", "1") != "0" else 0
+
+
+def _caps(ws, h=None, g=None):
+    """ws_floats argument of the launch-based sweeps / the plane weight gradients (include/arcvae_hip.h): what THIS workspace
+    allocated, in floats, for {hseq_t, dG_t, wt, wT} -- the library refuses (ARCVAE_ERR_ARG) a call whose kernel family, decided
+    at that call from the shape and the ARCVAE_* knobs, would need more.  h / g: other buffers standing in for the two rings."""
+    def n(t):
+        return 0 if t is None else t.numel() * t.element_size() // 4
+    h = ws.hseq_t if h is None else h
+    g = getattr(ws, "dG_t", None) if g is None else g
+    return (C.c_long * 4)(n(h), n(g), n(ws.wt), n(getattr(ws, "wT", None)))
 
 
 def _oct(ws, name: str) -> C.c_void_p:
@@ -220,7 +231,8 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
              ptr(enc.p("lstm_layer_0.Wx")), d.E, ptr(ws.table0), G, ptr(enc.p("lstm_layer_0.bias")), 0, s)
         need_wT = hasattr(ws, "wT") and not bptt_reduce_scatter_ok(ws, d)
         call("arcvae_enc_lstm_forward_persistent", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq),
-             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wT) if need_wT else C.c_void_p(0), ptr(ws.comb), ptr(ws.psync),
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wT) if need_wT else C.c_void_p(0), C.c_long(ws.wT.numel() if need_wT else 0),
+             ptr(ws.comb), ptr(ws.psync),
              start_signal if start_signal is not None else C.c_void_p(0), B, T, d.V, d.H, d.L,
              1 | (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0) | (_lstm_flags(ws) & _lib.LSTM_SPLIT3), ptr(ws.trace_fwd), s)
     else:
@@ -235,7 +247,7 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         if start_signal is not None:
             call("arcvae_gate_set", start_signal, 1, 1, s)
         call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
-             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, _lstm_flags(ws),
+             ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, _lstm_flags(ws), _caps(ws),
              _oct(ws, "h_oct"), ptr(ws.trace_fwd), s)
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
@@ -282,16 +294,16 @@ def decoder_forward_dense(dec: ParamStore, ws: Workspace, d: ModelDims, mode: in
             ws.dense_ws_fwd = torch.empty(n.value, dtype=torch.float32, device=ws.hact.device)
         mode &= ~_lib.DEC_NO_GPRE
         part(_lib.DEC_PART_HEAD)
-        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), C.c_void_p(0), ptr(ws.dense_ws_fwd), ws.B * d.V, d.H, d.L, 1,
-             stream_ptr())
+        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), C.c_void_p(0), ptr(ws.dense_ws_fwd), C.c_long(ws.dense_ws_fwd.numel()),
+             ws.B * d.V, d.H, d.L, 1, stream_ptr())
         part(_lib.DEC_PART_TAIL)
         return
     if keep_gpre and getattr(ws, "dense_ws", None) is not None:
         # MFMA-bound regime (StepEngine.workspace): layers 1 .. L-1 -- zero-state cells over B*V rows -- on the three-piece tile
         # kernels of the encoder's sweeps; `gpre` then holds the POST-activation gates (what their backward reads)
         part(_lib.DEC_PART_HEAD)
-        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), ptr(ws.gpre), ptr(ws.dense_ws), ws.B * d.V, d.H, d.L,
-             _lib.LSTM_BF16 if (ws.bf16_parts & 2) else 0, stream_ptr())
+        call("arcvae_dense_stack_forward", wx, bs, ptr(ws.hact), ptr(ws.gpre), ptr(ws.dense_ws), C.c_long(ws.dense_ws.numel()),
+             ws.B * d.V, d.H, d.L, _lib.LSTM_BF16 if (ws.bf16_parts & 2) else 0, stream_ptr())
         part(_lib.DEC_PART_TAIL)
         ws.dense_fwd = True
         return
@@ -325,7 +337,7 @@ def decoder_backward(dec: ParamStore, ws: Workspace, d: ModelDims, inv_count: fl
         # backward on the same kernels (dh_top in ddh[0] -> dh_0 in ddh[1]), then layer 0 and the token table
         part(_lib.DEC_PART_TAIL, ptr(ws.ddh))
         call("arcvae_dense_stack_backward", ptr(ws.gpre), ptr(ws.ddh[0]), ptr(ws.ddG), ptr(ws.ddh[1]), dwx, dbs,
-             ptr(ws.dense_ws), ws.B * d.V, d.H, d.L, _lib.LSTM_BF16 if (ws.bf16_parts & 2) else 0, s)
+             ptr(ws.dense_ws), C.c_long(ws.dense_ws.numel()), ws.B * d.V, d.H, d.L, _lib.LSTM_BF16 if (ws.bf16_parts & 2) else 0, s)
         part(_lib.DEC_PART_HEAD, ptr(ws.ddh[1]))
         return
     part(0, ptr(ws.ddh))
@@ -356,15 +368,17 @@ class Gates:
     (1 per step: the data-parallel step reduces the decoder's gradients early), NS / NA / NM steps finished by
     side / aux / main (the waiter's own ticket counter), ERR expired gates, PROBE self-test, H "the BPTT sweep has started"
     (1 per step, raised by the sweep's first launch: the heads' dcomb chain in front of it is complete, so their
-    parameter gradients may be formed -- on aux, while the first chunk is still being swept and aux has nothing else).
+    parameter gradients may be formed -- on aux, while the first chunk is still being swept and aux has nothing else),
+    HG "the heads' parameter gradients of this step are formed" (1 per step, raised by aux behind heads_wgrad: the
+    data-parallel step reduces that 1.58 MB bucket early, on side -- dp.EngineOps.seam_buckets).
     """
     STRIDE = 8
     LONG, SHORT = 16_000_000, 3_000    # polls (~1.5 us each): ~25 s before a gate gives up (a first RCCL collective
                                        # or a peer still capturing its graphs may hold main up for seconds); ~4 ms probe
-    P, Q, NS, NA, ERR, PROBE, R, NM, D, H = range(10)
+    P, Q, NS, NA, ERR, PROBE, R, NM, D, H, HG = range(11)
 
     def __init__(self, device):
-        self.mem = torch.zeros(10 * 32, dtype=torch.int32, device=device)
+        self.mem = torch.zeros(11 * 32, dtype=torch.int32, device=device)
         self._probed: Dict[Tuple[int, int], bool] = {}
 
     def word(self, i: int) -> C.c_void_p:
@@ -516,7 +530,7 @@ class EncoderBackwardPlan:
             # default shape: the reduce-scatter sweep with the weight gradients formed inside it
             enc = self.enc
             call("arcvae_enc_lstm_backward_fused", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.hseq),
-                 ptr(ws.x_tb), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), ptr(ws.psync),
+                 ptr(ws.x_tb), ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), C.c_long(ws.ppart.numel()), ptr(ws.psync),
                  sig, self._dwx[0], self._dwh[0], self._dbs[0], ptr(ws.dtable0), ws.B, ws.T, d.V, d.H, d.L, s0, s1,
                  chunk_index, ptr(ws.trace_bwd), stream_ptr())
             return
@@ -524,7 +538,7 @@ class EncoderBackwardPlan:
             # latency regime, default shape: persistent BPTT sweep in its reduce-scatter form, one launch per chunk
             # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
             call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
-                 ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), ptr(ws.psync), sig,
+                 ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), C.c_long(ws.ppart.numel()), ptr(ws.psync), sig,
                  ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0) | rearmed,
                  ptr(ws.trace_bwd), stream_ptr())
             return
@@ -537,7 +551,7 @@ class EncoderBackwardPlan:
         call("arcvae_enc_lstm_backward", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq), ptr(ws.dcomb),
              2 * d.H, ptr(ws.dG), ptr(ws.dG_t), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.wT), ws.B, ws.T, d.H, d.L, s0, s1,
              _lstm_flags(ws),  # no LSTM_RETILE: the forward of this step already wrote the BPTT weight layouts
-             _oct(ws, "dG_oct"), start_signal if start_signal is not None else C.c_void_p(0), ptr(ws.trace_bwd), stream_ptr())
+             _caps(ws), _oct(ws, "dG_oct"), start_signal if start_signal is not None else C.c_void_p(0), ptr(ws.trace_bwd), stream_ptr())
 
     def wgrad(self, t_lo: int, t_hi: int, first: bool, last: bool, parts: int = 3, table=None) -> None:
         """Weight gradients of the time range.  `table`: token-table workspace of this call (default ws.dtable0); the
@@ -558,15 +572,15 @@ class EncoderBackwardPlan:
             # throughput mode: one bf16 product per GEMM step.  Not beside a persistent sweep: there the matrix pipe is
             # idle anyway and what counts is what fits on the sweep's SIMDs (measured at bs 64: 1.077 vs 1.03 ms)
             parts |= _lib.WGRAD_BF16
-        elif getattr(ws, "pl_g", None) is not None and not self.persistent:
-            # 256..512 rows per GPU (per-step-launch BPTT, f32 operand copies): the call splits dG / h of its time range into
-            # three-piece planes itself (one elementwise pass) and runs the plane GEMMs -- 2.7x less matrix-pipe time than the
-            # exact-f32 tile GEMM beside the sweep, no re-splitting per tile
+        elif getattr(ws, "pl_g", None) is not None:
+            # 129..512 rows per GPU (persistent or per-step-launch BPTT, f32 gate gradients): the call splits dG / h of its time
+            # range into three-piece planes itself (one elementwise pass) and runs the plane GEMMs -- 2.7x less matrix-pipe time
+            # than the exact-f32 tile GEMM, no re-splitting per tile
             parts |= 2048 | 4096 | 16
             call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
                  ptr(ws.hseq), ptr(ws.dG), ptr(table if table is not None else ws.dtable0), ptr(ws.onehot),
                  ptr(enc.g("embedding.weight")), self._dwx[0], self._dwh[0], self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L,
-                 t_lo, t_hi, int(first), int(last), parts, ptr(ws.pl_h), ptr(ws.pl_g), stream_ptr())
+                 t_lo, t_hi, int(first), int(last), parts, ptr(ws.pl_h), ptr(ws.pl_g), _caps(ws, ws.pl_h, ws.pl_g), stream_ptr())
             return
         elif getattr(ws, "planes", False) and not self.persistent:
             # MFMA-bound regime, three-piece sweeps: the GEMMs read the sweeps' operand planes (all T slots kept) -- see
@@ -575,7 +589,7 @@ class EncoderBackwardPlan:
             call("arcvae_enc_lstm_wgrad", ptr(ws.x_tb), ptr(enc.p("embedding.weight")), ptr(enc.p("lstm_layer_0.Wx")),
                  ptr(ws.hseq), ptr(ws.dG), ptr(table if table is not None else ws.dtable0), ptr(ws.onehot),
                  ptr(enc.g("embedding.weight")), self._dwx[0], self._dwh[0], self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L,
-                 t_lo, t_hi, int(first), int(last), parts, ptr(ws.hseq_t), ptr(ws.dG_t), stream_ptr())
+                 t_lo, t_hi, int(first), int(last), parts, ptr(ws.hseq_t), ptr(ws.dG_t), _caps(ws), stream_ptr())
             return
         elif (not self.persistent and os.environ.get("ARCVAE_WGRAD_SPLIT3", "1") != "0"
               and (_lib.load().arcvae_enc_lstm_tiled_for(ws.B, d.H, d.L, _lstm_flags(ws)) & 2)):
@@ -598,7 +612,7 @@ class EncoderBackwardPlan:
              ptr(enc.g("embedding.weight")), self._dwx[0],
              self._dwh[0],
              self._dbs[0], ws.B, ws.T, d.V, d.E, d.H, d.L, t_lo, t_hi, int(first), int(last), parts,
-             _oct(ws, "h_oct"), _oct(ws, "dG_oct"), stream_ptr())
+             _oct(ws, "h_oct"), _oct(ws, "dG_oct"), None, stream_ptr())
 
 
 def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
@@ -733,9 +747,11 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
                 # the dcomb chain in front of the sweep is complete once the sweep has started
                 g.wait(g.H, g.NA, 1, 1)
                 plan.heads(2)
+                g.signal(g.HG, 1)
             g.wait(g.P, g.NA, g.STRIDE, g.STRIDE if last else 2 + c, advance=last)
             if c == 0 and not heads_early:
                 plan.heads(2)
+                g.signal(g.HG, 1)   # (every gated step, single process too: HG stays in lockstep with side's ticket counter)
             plan.wgrad(t_lo, t_hi, first, last,
                        8 if wx_on_side else (1 if (table_on_side or (last and tail_on_side)) else 3))
             if c == max(nc - 2, 0):
@@ -788,6 +804,7 @@ def _encoder_backward_gated_fused(plan: EncoderBackwardPlan, ws: Workspace, aux,
     def aux_seg():
         g.wait(g.P, g.NA, g.STRIDE, 2, advance=True)
         plan.heads(2)
+        g.signal(g.HG, 1)
         g.signal(g.Q, 1)
         g.signal(g.R, 1)
 
@@ -928,10 +945,15 @@ class StepEngine:
             # directly (arcvae_enc_lstm_wgrad parts bit 11: no f32 loads, no re-splitting) -- configs[2], the 2048-row leg
             lib = _lib.load()
             slots = lib.arcvae_enc_lstm_operand_slots(B, T, self.d.H, self.d.L, _lstm_flags(ws))
-            if slots > ws.hseq_t.shape[1]:
-                ws.hseq_t = torch.empty(self.d.L, slots, B * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
-                if train:
-                    ws.dG_t = torch.empty(self.d.L, slots, B * 4 * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
+            # (sizes from the library -- arcvae_enc_lstm_ws_floats: ring slots x slab, three-piece planes at 3/2 -- and every sweep
+            # call states these capacities back: a knob changed after this point is an ARCVAE_ERR_ARG, not an overrun)
+            need = (C.c_long * 4)()
+            _lib.check(lib.arcvae_enc_lstm_ws_floats(B, T, self.d.H, self.d.L, _lstm_flags(ws), need), "arcvae_enc_lstm_ws_floats")
+            if need[0] > ws.hseq_t.numel():
+                ws.hseq_t = torch.empty(self.d.L, slots, need[0] // (self.d.L * slots), dtype=torch.float32, device=self.device)
+            if train and need[1] > ws.dG_t.numel():
+                ws.dG_t = torch.empty(self.d.L, slots, need[1] // (self.d.L * slots), dtype=torch.float32, device=self.device)
+            assert need[2] <= ws.wt.numel() and (not train or need[3] <= ws.wT.numel())
             # ... and the dense decoder's layers 1 .. L-1 (zero-state cells over B*V rows) on the same kernels
             # (only where the encoder's sweeps are launch-based tile kernels themselves: beside a PERSISTENT sweep the tile kernels'
             # blocks -- 370-420 registers, 64-70 KB of LDS -- cannot be resident and the two serialise: bs 128 1.63 -> 2.00 ms)
@@ -959,7 +981,7 @@ class StepEngine:
             conv = os.environ.get("ARCVAE_WGRAD_CONVERT", "0")
             if (train and not ws.planes and not ws.bf16 and B % 32 == 0 and self.d.H % 64 == 0 and conv != "0"
                     and (conv == "2" or B >= 256) and not (lib.arcvae_enc_lstm_tiled_for(B, self.d.H, self.d.L, _lstm_flags(ws)) & 2)
-                    and not bptt_reduce_scatter_ok(ws, self.d)):
+                    and (B > 128 or not bptt_reduce_scatter_ok(ws, self.d))):
                 ws.pl_h = torch.empty(self.d.L * T * B * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
                 ws.pl_g = torch.empty(self.d.L * T * B * 4 * self.d.H * 3 // 2, dtype=torch.float32, device=self.device)
             self._ws[key] = ws

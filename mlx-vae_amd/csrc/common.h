@@ -4,10 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ARCVAE_OK 0
-#define ARCVAE_ERR_ARG (-1)      // bad shape / null pointer / unsupported size
-#define ARCVAE_ERR_LAUNCH (-2)   // hipGetLastError() after a launch
-#define ARCVAE_ERR_DEVICE (-3)   // wrong device / no gfx950 device
+// The PUBLIC header is the single source of the C ABI: error codes, flag bits and every extern "C" prototype.  Including it here
+// (with the real hipStream_t behind arcvae_stream_t) makes a definition in this directory that drifts from its declaration a
+// compile error -- csrc/ used to re-declare flags and prototypes in ops.h, and include/arcvae_hip.h could (and did) go stale.
+#define ARCVAE_HIP_BUILD 1
+#include "arcvae_hip.h"
 
 #define ARCVAE_MAX_LAYERS 8
 

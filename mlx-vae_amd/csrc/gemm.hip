@@ -1340,6 +1340,12 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
         if (loader) {
             if (ks + 1 < kend) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // Invariant of the ring: the stage the loaders refill right behind THIS barrier is the one the consumers
+            // read at K-step ks - 1, so every fragment read of ks - 1 must have RETURNED before a consumer arrives here.  The MFMAs
+            // that consumed them are no memory operations and gfx950's barrier carries no implicit waitcnt, so say it explicitly
+            // (free: those products were issued already) instead of relying on where the scheduler puts the waitcnt.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");       // (compiler fence: no LDS read of this K-step may be scheduled above the barrier)

@@ -2911,6 +2911,25 @@ extern "C" int arcvae_enc_lstm_operand_slots(int B, int T, int H, int L, int fla
     return operand_ring_slots(B, T, H, L, flags);
 }
 
+// Floats of {hseq_t, dG_t, wt, wT} the launch-based sweeps of this shape use under the CURRENT kernel-family knobs: ring slots x
+// slab size, slabs and weight copies at 3/2 of their f32 size where that sweep runs in the three-piece form.  What
+// arcvae_enc_lstm_ws_floats reports and what every sweep call checks its caller's capacities against (ws_floats): the family is
+// re-decided at every call (the tests toggle the knobs), so an undersized buffer is refused here instead of being written past.
+static inline void lstm_ws_need(int B, int T, int H, int L, int flags, long need[4]) {
+    const long sH = (long)B * H, sG = (long)B * 4 * H, w = (long)H * 4 * H;
+    const bool f3 = fwd_split3(B, H, L, flags), b3 = bwd_split3(B, H, L, flags);
+    const long slots = operand_ring_slots(B, T, H, L, flags);
+    need[0] = (long)L * slots * (f3 ? sH * 3 / 2 : sH);
+    need[1] = (long)L * slots * (b3 ? sG * 3 / 2 : sG);
+    need[2] = (long)(2 * L - 1) * (f3 ? w * 3 / 2 : w);
+    need[3] = (long)(2 * L - 1) * (b3 ? w * 3 / 2 : w);
+}
+extern "C" int arcvae_enc_lstm_ws_floats(int B, int T, int H, int L, int flags, long* floats) {
+    if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || !floats) return ARCVAE_ERR_ARG;
+    lstm_ws_need(B, T, H, L, flags, floats);
+    return ARCVAE_OK;
+}
+
 extern "C" int arcvae_enc_lstm_tiled(int B, int H, int L) {
     if (B <= 0 || L <= 0 || !hidden_ok(H)) return 0;
     return (fwd_tile_choice(B, H, L, 0) != 0 ? 1 : 0) | (bwd_tile_choice(B, H, L, 0) != 0 ? 2 : 0);
@@ -2935,10 +2954,15 @@ extern "C" int arcvae_enc_lstm_tiled_for(int B, int H, int L, int flags) {
 extern "C" int arcvae_enc_lstm_forward(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                        const float* const* Wh, const float* const* bias, float* hseq,
                                        float* hseq_t, float* cseq, float* gseq, float* wt, float* wT_bwd, int B,
-                                       int T, int V, int H, int L, int flags, void* h_oct, unsigned long long* trace,
-                                       hipStream_t stream) {
-    if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !hseq_t || !cseq || !gseq || !wt) return ARCVAE_ERR_ARG;
+                                       int T, int V, int H, int L, int flags, const long* ws_floats, void* h_oct,
+                                       unsigned long long* trace, hipStream_t stream) {
+    if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !hseq_t || !cseq || !gseq || !wt || !ws_floats) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || V <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H)) return ARCVAE_ERR_ARG;
+    {   // the caller's buffers against what the kernel family chosen at THIS call writes (rings: slots x slab, planes at 3/2)
+        long need[4];
+        lstm_ws_need(B, T, H, L, flags, need);
+        if (ws_floats[0] < need[0] || ws_floats[2] < need[2] || (wT_bwd && ws_floats[3] < need[3])) return ARCVAE_ERR_ARG;
+    }
     for (int l = 0; l < L; ++l)
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
@@ -3020,11 +3044,16 @@ extern "C" int arcvae_enc_lstm_persistent_ok(int B, int T, int H, int L) { retur
 // sync_ws[500] != 0 means a block gave up waiting (results invalid: fall back to arcvae_enc_lstm_forward).
 extern "C" int arcvae_enc_lstm_forward_persistent(const int32_t* x_tb, const float* table0, const float* const* Wx,
                                                   const float* const* Wh, const float* const* bias, float* hseq,
-                                                  float* cseq, float* gseq, float* wT_bwd, float* comb,
+                                                  float* cseq, float* gseq, float* wT_bwd, long wT_bwd_floats, float* comb,
                                                   unsigned* sync_ws, unsigned* start_signal, int B, int T, int V, int H,
                                                   int L, int flags, unsigned long long* trace, hipStream_t stream) {
     if (!x_tb || !table0 || !Wx || !Wh || !bias || !hseq || !cseq || !gseq || !sync_ws) return ARCVAE_ERR_ARG;
     if (V <= 0 || !persist_shape_ok(B, T, H, L)) return ARCVAE_ERR_ARG;
+    if (wT_bwd) {
+        long need[4];
+        lstm_ws_need(B, T, H, L, flags, need);
+        if (wT_bwd_floats < need[3]) return ARCVAE_ERR_ARG;
+    }
     for (int l = 0; l < L; ++l)
         if (!Wh[l] || (l > 0 && (!Wx[l] || !bias[l]))) return ARCVAE_ERR_ARG;
     int rc;
@@ -3128,6 +3157,19 @@ extern "C" int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L) {
 // 2 if the persistent sweeps of this shape run in their two-group form (two blocks per CU, the XCD's 17..32 rows as two
 // independent 16-row recurrences: H = 256, L <= 2, 129 <= B <= 256), else 1.  A two-group step re-arms 4352 words of
 // sync_ws (arcvae_enc_prologue n_sync), a one-group step 848.
+// floats of part_ws the reduce-scatter sweep of this shape uses: groups of 8 rows per XCD (1 / 2 / 4; the two-group form: 2 x 2)
+// x two tick parities x (2L-1) slots x [8 XCDs][32 consumers][32 producers][64]
+static inline long bwd_rs_part_floats(int B, int H, int L) {
+    const int rows_x = ceil_div(B, 8);
+    const int rgn = persist_two_groups(B, H, L, 2) ? 4 : (rows_x <= 8 ? 1 : (rows_x <= 16 ? 2 : 4));
+    return (long)rgn * 2 * (2 * L - 1) * 8 * 32 * 32 * 64;
+}
+// Floats of part_ws (the partial sums in flight) arcvae_enc_lstm_backward_persistent_rs / _fused use for this shape under the
+// current knobs, or 0 where that sweep does not run.
+extern "C" long arcvae_enc_lstm_bwd_rs_part_floats(int B, int T, int H, int L) {
+    return arcvae_enc_lstm_bwd_rs_ok(B, T, H, L) == 1 ? bwd_rs_part_floats(B, H, L) : 0;
+}
+
 extern "C" int arcvae_enc_lstm_persist_groups(int B, int H, int L) {
     return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && B > 0 && persist_two_groups(B, H, L, 3)) ? 2 : 1;
 }
@@ -3141,12 +3183,13 @@ struct FusedWgrad {
     const float* hseq; const int32_t* x_tb; float* const* dWx; float* const* dWh; float* const* dbias; float* dtable; int V;
 };
 int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* cseq, const float* gseq,
-                  const float* dh_top, int ld_dh_top, float* dG, float* dcs, float* dxs, float* part_ws,
+                  const float* dh_top, int ld_dh_top, float* dG, float* dcs, float* dxs, float* part_ws, long part_ws_floats,
                   unsigned* sync_ws, unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end,
                   int chunk_index, unsigned long long* trace, const FusedWgrad* fused, int flags, hipStream_t stream) {
     if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dcs || !dxs || !part_ws || !sync_ws) return ARCVAE_ERR_ARG;
     if (H != 256 || L < 1 || L > 2 || B < 1 || B > 256 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
+    if (part_ws_floats < bwd_rs_part_floats(B, H, L)) return ARCVAE_ERR_ARG;   // (the form is re-decided at every call: refuse, never overrun)
     const int rows_x = ceil_div(B, 8);                                  // rows per XCD
     // two-group form (17..32 rows per XCD): two blocks per CU, each group an independent 16-row recurrence (R16 tile form)
     const bool two = !fused && !(flags & ARCVAE_PERSIST_BF16) && persist_two_groups(B, H, L, 2);
@@ -3259,11 +3302,11 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
 
 extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* const* Wh, const float* cseq,
                                                       const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
-                                                      float* dcs, float* dxs, float* part_ws, unsigned* sync_ws,
-                                                      unsigned* start_signal, int B, int T, int H, int L, int s_begin,
-                                                      int s_end, int chunk_index, int flags, unsigned long long* trace,
-                                                      hipStream_t stream) {
-    return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, sync_ws, start_signal, B, T, H, L,
+                                                      float* dcs, float* dxs, float* part_ws, long part_ws_floats,
+                                                      unsigned* sync_ws, unsigned* start_signal, int B, int T, int H, int L,
+                                                      int s_begin, int s_end, int chunk_index, int flags,
+                                                      unsigned long long* trace, hipStream_t stream) {
+    return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, part_ws_floats, sync_ws, start_signal, B, T, H, L,
                          s_begin, s_end, chunk_index, trace, nullptr, flags, stream);
 }
 
@@ -3275,13 +3318,13 @@ extern "C" int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, co
 extern "C" int arcvae_enc_lstm_backward_fused(const float* const* Wx, const float* const* Wh, const float* cseq,
                                               const float* gseq, const float* hseq, const int32_t* x_tb,
                                               const float* dh_top, int ld_dh_top, float* dG, float* dcs, float* dxs,
-                                              float* part_ws, unsigned* sync_ws, unsigned* start_signal,
+                                              float* part_ws, long part_ws_floats, unsigned* sync_ws, unsigned* start_signal,
                                               float* const* dWx, float* const* dWh, float* const* dbias,
                                               float* dtable_ws, int B, int T, int V, int H, int L, int s_begin, int s_end,
                                               int chunk_index, unsigned long long* trace, hipStream_t stream) {
     FusedWgrad f;
     f.hseq = hseq; f.x_tb = x_tb; f.dWx = dWx; f.dWh = dWh; f.dbias = dbias; f.dtable = dtable_ws; f.V = V;
-    return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, sync_ws, start_signal, B, T, H, L,
+    return launch_bwd_rs(Wx, Wh, cseq, gseq, dh_top, ld_dh_top, dG, dcs, dxs, part_ws, part_ws_floats, sync_ws, start_signal, B, T, H, L,
                          s_begin, s_end, chunk_index, trace, &f, 0, stream);
 }
 
@@ -3299,14 +3342,19 @@ extern "C" int arcvae_enc_lstm_backward_fused(const float* const* Wx, const floa
 extern "C" int arcvae_enc_lstm_backward(const float* const* Wx, const float* const* Wh, const float* cseq,
                                         const float* gseq, const float* dh_top, int ld_dh_top, float* dG,
                                         float* dG_t, float* dcs, float* dxs, float* wT, int B, int T, int H,
-                                        int L, int s_begin, int s_end, int flags, void* dG_oct, unsigned* start_signal,
-                                        unsigned long long* trace, hipStream_t stream) {
+                                        int L, int s_begin, int s_end, int flags, const long* ws_floats, void* dG_oct,
+                                        unsigned* start_signal, unsigned long long* trace, hipStream_t stream) {
     const int retile = flags & ARCVAE_LSTM_RETILE;
     const bool b16 = bwd_bf16(B, H, L, flags), s3 = bwd_split3(B, H, L, flags);
     const bool oct = b16 && dG_oct && (B % 16) == 0;
-    if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT) return ARCVAE_ERR_ARG;
+    if (!Wx || !Wh || !cseq || !gseq || !dh_top || !dG || !dG_t || !dcs || !dxs || !wT || !ws_floats) return ARCVAE_ERR_ARG;
     if (B <= 0 || T <= 0 || L <= 0 || L > ARCVAE_MAX_LAYERS || !hidden_ok(H) || ld_dh_top < H)
         return ARCVAE_ERR_ARG;
+    {   // (as in arcvae_enc_lstm_forward: an undersized ring or weight copy is an argument error, never an overrun)
+        long need[4];
+        lstm_ws_need(B, T, H, L, flags, need);
+        if (ws_floats[1] < need[1] || ws_floats[3] < need[3]) return ARCVAE_ERR_ARG;
+    }
     const int S = T + 2 * (L - 1);
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     const long sH = (long)B * H, sG = (long)B * 4 * H;
@@ -3499,8 +3547,9 @@ extern "C" int arcvae_dense_stack_ws_floats(long R, int H, int L, long* floats) 
 // [L] of device pointers (entry 0 unused).
 // flags bit 0: forward only (sampler) -- gates / cell states / the backward's weight planes / the top layer's planes are not written.
 extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* const* bias, float* hact, float* gates, float* ws,
-                                          long R, int H, int L, int flags, hipStream_t stream) {
+                                          long ws_floats, long R, int H, int L, int flags, hipStream_t stream) {
     if (!Wx || !bias || !hact || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
+    if (ws_floats < dense_ws(nullptr, R, H, L).total) return ARCVAE_ERR_ARG;
     const bool fwd_only = (flags & 1) != 0, b16 = (flags & ARCVAE_LSTM_BF16) != 0;   // bit 1: throughput mode (bf16 operands)
     if ((!fwd_only && !gates) || (fwd_only && b16)) return ARCVAE_ERR_ARG;
     const int G = 4 * H, Ri = (int)R;
@@ -3548,8 +3597,10 @@ extern "C" int arcvae_dense_stack_forward(const float* const* Wx, const float* c
 // for l = L-1 .. 1 and dh0 [R, H] = dG_1 . Wx_1 (the input of dec_l0_bwd_kernel).  dG [R, 4H]: scratch (every layer's gate
 // gradients pass through it).  `ws` as the forward left it.
 extern "C" int arcvae_dense_stack_backward(const float* gates, const float* dh_top, float* dG, float* dh0, float* const* dWx,
-                                           float* const* dbias, float* ws, long R, int H, int L, int flags, hipStream_t stream) {
+                                           float* const* dbias, float* ws, long ws_floats, long R, int H, int L, int flags,
+                                           hipStream_t stream) {
     if (!gates || !dh_top || !dG || !dh0 || !dWx || !dbias || !ws || !arcvae_dense_stack_ok(R, H, L)) return ARCVAE_ERR_ARG;
+    if (ws_floats < dense_ws(nullptr, R, H, L).total) return ARCVAE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(dh_top) % 16) != 0) return ARCVAE_ERR_ARG;
     const int G = 4 * H, Ri = (int)R;
     const DenseWs w = dense_ws(ws, R, H, L);
@@ -3625,10 +3676,14 @@ extern "C" int arcvae_enc_lstm_wgrad(const int32_t* x_tb, const float* emb, cons
                                      const float* hseq, const float* dG, float* dtable_ws, float* onehot_ws,
                                      float* dEmb, float* const* dWx, float* const* dWh, float* const* dbias,
                                      int B, int T, int V, int E, int H, int L, int t_lo, int t_hi, int first,
-                                     int last, int parts, const void* h_oct, const void* dG_oct, hipStream_t stream) {
+                                     int last, int parts, const void* h_oct, const void* dG_oct, const long* ws_floats,
+                                     hipStream_t stream) {
     if (!x_tb || !emb || !Wx0 || !hseq || !dG || !dtable_ws || !onehot_ws || !dEmb || !dWx || !dWh || !dbias)
         return ARCVAE_ERR_ARG;
     if (t_lo < 0 || t_hi > T || t_lo > t_hi) return ARCVAE_ERR_ARG;
+    if ((parts & 2048) && h_oct && dG_oct) {   // plane rings with ALL T slots: [L,T,B*H*3/2] and [L,T,B*4H*3/2] floats
+        if (!ws_floats || ws_floats[0] < (long)L * T * B * H * 3 / 2 || ws_floats[1] < (long)L * T * B * 4 * H * 3 / 2) return ARCVAE_ERR_ARG;
+    }
     const int G = 4 * H, TB = T * B;
     const long lH = (long)TB * H, lG = (long)TB * G;
     int rc;

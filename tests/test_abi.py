@@ -12,7 +12,7 @@ def _declared_args():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\bint\s+(arcvae_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long)\s+(arcvae_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         decls[m.group(1)] = [" ".join(a.split()) for a in m.group(2).split(",") if a.strip()]
     return decls
 
@@ -71,6 +71,35 @@ def test_binding_signatures_match_header_types():
         got = _lib.SIGNATURES[name]
         for i, (w, g, d) in enumerate(zip(want, got, decls)):
             assert w is g or (w == g), (name, i, d, w, g)
+
+
+def test_csrc_takes_its_declarations_from_the_public_header():
+    """include/arcvae_hip.h is the ONLY place the C ABI is declared: csrc/common.h includes it (with hipStream_t behind
+    arcvae_stream_t), so a definition that drifts from its declaration is a compile error; nothing in csrc re-declares a flag
+    bit, an error code or an extern "C" prototype (round 3's header had gone stale that way: ARCVAE_LSTM_SPLIT3 and the 3/2
+    plane sizes lived only in csrc/ops.h)."""
+    src_dir = os.path.join(ROOT, "mlx-vae_amd", "csrc")
+    header = open(HEADER).read()
+    public = set(re.findall(r"^#define\s+(ARCVAE_\w+)", header, flags=re.M))
+    assert {"ARCVAE_LSTM_SPLIT3", "ARCVAE_LSTM_BF16", "ARCVAE_ERR_ARG", "ARCVAE_DEC_PART_TAIL"} <= public
+    assert '#include "arcvae_hip.h"' in open(os.path.join(src_dir, "common.h")).read()
+    assert "-I../../include" in open(os.path.join(src_dir, "Makefile")).read()
+    assert not re.search(r'^\s*extern "C"', open(os.path.join(src_dir, "ops.h")).read(), flags=re.M)
+    for fn in os.listdir(src_dir):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(src_dir, fn)).read()
+        again = set(re.findall(r"^\s*#define\s+(ARCVAE_\w+)", text, flags=re.M)) & (public - {"ARCVAE_HIP_BUILD"})
+        assert not again, f"{fn} re-defines {sorted(again)} (declared in include/arcvae_hip.h)"
+    # every entry point the header declares is DEFINED extern "C" in csrc under exactly that name
+    defined = set()
+    for fn in os.listdir(src_dir):
+        if fn.endswith(".hip"):
+            defined |= set(re.findall(r'extern "C"\s+(?:int|long)\s+(arcvae_\w+)\s*\(', open(os.path.join(src_dir, fn)).read()))
+            for blk in re.findall(r'extern "C"\s*\{(.*?)\n\}', open(os.path.join(src_dir, fn)).read(), flags=re.S):
+                defined |= set(re.findall(r"^(?:int|long)\s+(arcvae_\w+)\s*\(", blk, flags=re.M))
+    missing = set(_declared()) - defined
+    assert not missing, f"declared in the header, no extern \"C\" definition found in csrc: {sorted(missing)}"
 
 
 def test_header_keeps_no_hidden_host_state():

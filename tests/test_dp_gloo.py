@@ -41,6 +41,10 @@ class OracleOps:
         self.scalars = {}
         self.enc_names = [k for k in params if k.startswith("encoder.")]
         self.dec_names = [k for k in params if k.startswith("decoder.")]
+        # the encoder HEADS' parameters (SURVEY 8e's second bucket: complete right behind the stats seam) / the LSTM stack's
+        self.head_names = [k for k in self.enc_names if k.split(".")[1] in ("condition_fc", "fc_mu", "fc_logvar_hidden", "fc_logvar")]
+        self.lstm_names = [k for k in self.enc_names if k not in self.head_names]
+        self.seam_issue_early = False               # no device-side gate here: the heads bucket is reduced behind backward_local
         self.enc_grad = None
         self.dec_grad = None
         self.m = {k: np.zeros_like(v, dtype=np.float64) for k, v in params.items()}
@@ -102,14 +106,20 @@ class OracleOps:
             v.grad = None
         self._latent_part.backward()               # the encoder only: the reconstruction term never reaches it (Q2)
         g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
-        self.enc_grad = torch.cat([g[k].reshape(-1) for k in self.enc_names]).clone()
+        self.heads_grad = torch.cat([g[k].reshape(-1) for k in self.head_names]).clone()
+        self.lstm_grad = torch.cat([g[k].reshape(-1) for k in self.lstm_names]).clone()
         assert all(float(g[k].abs().max()) == 0.0 for k in self.dec_names)
 
     def early_buckets(self):
         return [self.dec_grad]
 
+    def seam_buckets(self):
+        self.order.append("seam_buckets")
+        return [self.heads_grad]
+
     def late_buckets(self):
-        return [self.enc_grad]
+        self.order.append("late_buckets")
+        return [self.lstm_grad]
 
     def early_context(self):
         return contextlib.nullcontext()
@@ -119,12 +129,13 @@ class OracleOps:
         self.scalars = dict(total=recon + float(self._latent_part), recon=recon, kl=self._kl, mi=self._mi)
         params = {k: v.detach().numpy().copy() for k, v in self.p.items()}
         grads = {}
-        for names, flat in ((self.enc_names, self.enc_grad), (self.dec_names, self.dec_grad)):
+        for names, flat in ((self.lstm_names, self.lstm_grad), (self.head_names, self.heads_grad), (self.dec_names, self.dec_grad)):
             o = 0
             for k in names:
                 n = params[k].size
                 grads[k] = flat[o:o + n].numpy().reshape(params[k].shape)
                 o += n
+        self.enc_grad = torch.cat([torch.as_tensor(grads[k]).reshape(-1) for k in self.enc_names])
         O.adam_update(params, grads, self.m, self.v, self.lr)
         self.p = {k: torch.tensor(v, dtype=DT, requires_grad=True) for k, v in params.items()}
 
@@ -137,25 +148,59 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+class _CountingGroupCalls:
+    """Records (communicator, elements) of every all-reduce DataParallelStep issues: which bucket went through which group."""
+
+    def __init__(self, step):
+        self.step, self.calls = step, []
+        inner = step._all_reduce
+
+        def spy(t, group=None):
+            if t is not None:
+                self.calls.append(("early" if group is step.early_group else "main", int(t.numel())))
+            inner(t, group)
+        step._all_reduce = spy
+
+
+def _worker(rank, world, port, ret, sub_ranks=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    from arcvae_hip.dp import DataParallelStep
+    from arcvae_hip.dp import DataParallelStep, agree_all
+    group, nranks = None, world
+    if sub_ranks is not None:
+        # a 2-rank SUBGROUP of a 3-rank job drives the step (ADVICE r3): new_group is collective over the default group, so
+        # the outsider creates both communicators too -- and then takes no part in any collective of the step
+        group = dist.new_group(ranks=sub_ranks)
+        early = dist.new_group(ranks=sub_ranks)
+        nranks = len(sub_ranks)
+        if rank not in sub_ranks:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        # the agreement EngineOps makes on its form: on the subgroup (on the default group the outsider would be missing)
+        assert agree_all(rank == sub_ranks[0], group, "cpu") is False and agree_all(True, group, "cpu") is True
     cfg, B, T = TINY, 6, 10
     params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
-    sl = slice(rank * B // world, (rank + 1) * B // world)
+    me = rank if sub_ranks is None else sub_ranks.index(rank)
+    sl = slice(me * B // nranks, (me + 1) * B // nranks)
     ops = OracleOps(cfg, params, x[sl], cond[sl], eps[sl], coins, T, 2e-4, B)
-    step = DataParallelStep(ops)
-    assert step.world == world
+    step = DataParallelStep(ops, group=group, early_group=early if sub_ranks is not None else None)
+    assert step.world == nranks
     # two communicators: the early (decoder) bucket does not share one with the stats seam / the late bucket
     assert step.early_group is not None and step.early_group is not step.group
+    spy = _CountingGroupCalls(step)
     step.step()
-    # the decoder's reduces are issued before the stats seam (they overlap the encoder's sweeps on the GPU)
-    assert ops.order == ["forward_local", "recon_local", "early_done", "backward_local"], ops.order
+    # the decoder's reduces are issued before the stats seam (they overlap the encoder's sweeps on the GPU); the encoder heads'
+    # bucket follows the backward's enqueue (on the GPU: a device-side gate, issued with the early buckets), the LSTM bucket last
+    assert ops.order == ["forward_local", "recon_local", "early_done", "backward_local", "seam_buckets", "late_buckets"], ops.order
+    # which communicator carried what, in issue order (SURVEY 8e): {CE sum, decoder, heads} early; {stats, LSTM + embedding} main
+    assert spy.calls == [("early", 1), ("early", ops.dec_grad.numel()), ("main", 2 * cfg.Z + 3),
+                         ("early", ops.heads_grad.numel()), ("main", ops.lstm_grad.numel())], spy.calls
+    assert 0 < ops.heads_grad.numel() < ops.lstm_grad.numel()
     out = {k: v.detach().numpy() for k, v in ops.p.items()}
-    if rank == 0:
+    if me == 0:
         ret["params"] = out
         ret["scalars"] = ops.scalars
         ret["enc_grad"] = ops.enc_grad.numpy()
@@ -165,11 +210,14 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one_process_global_batch():
-    world = 2
+@pytest.mark.parametrize("world,sub_ranks", [(2, None), (3, [0, 2])])
+def test_two_ranks_equal_one_process_global_batch(world, sub_ranks):
+    """(3, [0, 2]): the same step driven by a 2-rank SUBGROUP of a 3-rank job -- every collective of the driver, its second
+    communicator and the form agreement stay inside the subgroup (rank 1 makes none of those calls; a collective on the
+    default group would hang here)."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, sub_ranks), nprocs=world, join=True)
     cfg, B, T = TINY, 6, 10
     params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
     p64 = {k: v.astype(np.float64) for k, v in params.items()}

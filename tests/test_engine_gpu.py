@@ -669,3 +669,70 @@ def test_hypothesis_shapes_in_the_tile_regime(monkeypatch):
         del eng, enc, dec
 
     run()
+
+
+def test_undersized_operand_rings_are_argument_errors_not_overruns(monkeypatch):
+    """The ring-size contract of the launch-based sweeps (include/arcvae_hip.h, round 4; VERDICT r3 item 3 / ADVICE r3): the
+    library re-decides the kernel family -- and with it the ring's slot count (16, or T where the weight gradients read the operand
+    planes) and the slab size (3/2 in the three-piece form) -- at EVERY call from the shape, the flags and the ARCVAE_* knobs,
+    while the caller sized its buffers earlier.  Every sweep call therefore states its capacities (ws_floats) and a call that
+    would need more is refused with ARCVAE_ERR_ARG before anything is launched.  Here: a workspace cached under the default knobs
+    (per-step kernels, 16-slot rings), then the tile regime forced on (all T = 24 slots of three-piece planes)."""
+    import ctypes as C
+    from arcvae_hip import _lib
+    import arcvae_hip.engine as E
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=64, latent_dim=16, num_conditions=1, num_layers=2)
+    B, T = 64, 24
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    monkeypatch.setenv("ARCVAE_PERSIST", "0")
+    eng, enc, dec = build_engine(cfg, params)
+    eng.mode = "eager"
+    eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)       # sizes and caches the (B, T) workspace
+    torch.cuda.synchronize()
+    ws = eng.workspace(B, T, True)
+    assert ws.hseq_t.shape[1] == 16
+    lib = _lib.load()
+    need = (C.c_long * 4)()
+    monkeypatch.setenv("ARCVAE_STEP_TILE", "4")                                # the knob changes AFTER the workspace was cached
+    assert lib.arcvae_enc_lstm_ws_floats(B, T, cfg.H, cfg.L, _lib.LSTM_SPLIT3, need) == 0
+    assert lib.arcvae_enc_lstm_operand_slots(B, T, cfg.H, cfg.L, _lib.LSTM_SPLIT3) == T
+    assert need[0] == cfg.L * T * B * cfg.H * 3 // 2 > ws.hseq_t.numel() and need[1] > ws.dG_t.numel()
+    # the entry points themselves: exact error code, called with the capacities of the 16-slot rings
+    d = eng.d
+    wx, _k1 = E._layer_ptrs(enc, d.L, "Wx", skip0=True)
+    wh, _k2 = E._layer_ptrs(enc, d.L, "Wh")
+    bs, _k3 = E._layer_ptrs(enc, d.L, "bias", skip0=True)
+    before = ws.hseq.clone()
+    rc = lib.arcvae_enc_lstm_forward(_lib.ptr(ws.x_tb), _lib.ptr(ws.table0), wx, wh, bs, _lib.ptr(ws.hseq), _lib.ptr(ws.hseq_t),
+                                     _lib.ptr(ws.cseq), _lib.ptr(ws.gseq), _lib.ptr(ws.wt), _lib.ptr(ws.wT), B, T, d.V, d.H, d.L,
+                                     _lib.LSTM_SPLIT3, E._caps(ws), C.c_void_p(0), C.c_void_p(0), _lib.stream_ptr())
+    assert rc == -1, rc                                                         # ARCVAE_ERR_ARG
+    rc = lib.arcvae_enc_lstm_backward(wx, wh, _lib.ptr(ws.cseq), _lib.ptr(ws.gseq), _lib.ptr(ws.dcomb), 2 * d.H, _lib.ptr(ws.dG),
+                                      _lib.ptr(ws.dG_t), _lib.ptr(ws.dcs), _lib.ptr(ws.dxs), _lib.ptr(ws.wT), B, T, d.H, d.L, 0,
+                                      T + 2 * (d.L - 1), _lib.LSTM_SPLIT3, E._caps(ws), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0),
+                                      _lib.stream_ptr())
+    assert rc == -1, rc
+    rc = lib.arcvae_enc_lstm_forward(_lib.ptr(ws.x_tb), _lib.ptr(ws.table0), wx, wh, bs, _lib.ptr(ws.hseq), _lib.ptr(ws.hseq_t),
+                                     _lib.ptr(ws.cseq), _lib.ptr(ws.gseq), _lib.ptr(ws.wt), _lib.ptr(ws.wT), B, T, d.V, d.H, d.L,
+                                     _lib.LSTM_SPLIT3, None, C.c_void_p(0), C.c_void_p(0), _lib.stream_ptr())
+    assert rc == -1, rc                                                         # no capacities given: refused as well
+    torch.cuda.synchronize()
+    assert torch.equal(ws.hseq, before)                                         # nothing was launched
+    # ... and the plane weight gradients: rings that do not hold all T slots are refused
+    rc = lib.arcvae_enc_lstm_wgrad(_lib.ptr(ws.x_tb), _lib.ptr(enc.p("embedding.weight")), _lib.ptr(enc.p("lstm_layer_0.Wx")),
+                                   _lib.ptr(ws.hseq), _lib.ptr(ws.dG), _lib.ptr(ws.dtable0), _lib.ptr(ws.onehot),
+                                   _lib.ptr(enc.g("embedding.weight")), E._layer_ptrs(enc, d.L, "Wx", grad=True)[0],
+                                   E._layer_ptrs(enc, d.L, "Wh", grad=True)[0], E._layer_ptrs(enc, d.L, "bias", grad=True)[0],
+                                   B, T, d.V, d.E, d.H, d.L, 0, T, 1, 1, 1 | 16 | 2048, _lib.ptr(ws.hseq_t), _lib.ptr(ws.dG_t),
+                                   E._caps(ws), _lib.stream_ptr())
+    assert rc == -1, rc
+    # through the engine: the cached workspace meets the changed knob as an exception at that step, not as a fault
+    with pytest.raises(_lib.ArcvaeHipError):
+        eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    # a fresh engine under the new knob sizes its rings from the library and runs
+    eng2, enc2, dec2 = build_engine(cfg, params)
+    out = eng2.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng2.check_gates()
+    assert eng2.workspace(B, T, True).hseq_t.shape[1] == T and np.isfinite(float(out["total_loss"]))

@@ -297,3 +297,54 @@ def test_copy_buffers_one_launch():
         got = d.cpu().numpy()
         assert np.array_equal(got[o:o + n], s.cpu().numpy()[o:o + n])
         assert (got[:o] == 255).all() and (got[o + n:] == 255).all()      # nothing outside the range was touched
+
+
+def test_plane_gemm_with_pointers_whose_low_half_has_the_top_bit_set():
+    """The round-3 memory fault, pinned (DESIGN_HISTORY round-3 log): wgrad_planes_kernel moves its problem's pointers
+    into scalar registers half by half with v_readfirstlane, whose builtin returns a SIGNED int -- assembled without an unsigned
+    cast, a low half >= 0x80000000 sign-extended over the high half (fault address 0xffffd7560000; the earlier form that
+    broadcast only the low half faulted at 0x35a54000 ...).  Whether a run hit it depended on where the allocator had put the
+    buffers, so the plane tests passed either way.  Here every pointer the kernel broadcasts -- both operand-plane buffers, the
+    output and the bias-sum rider -- is carved out of a large allocation at addresses whose low 32 bits have the top bit set, and
+    the result is checked against a float64 product."""
+    import ctypes as C
+    from arcvae_hip import _lib
+    lib = _lib.load()
+    B, H, L, T, V, E = 32, 64, 2, 4, 20, 16
+    G = 4 * H
+    big = torch.empty(6 * 2 ** 30, dtype=torch.uint8, device="cuda")
+    base = big.data_ptr()
+    off = (0x80000000 - (base & 0xffffffff)) % 2 ** 32          # first byte whose low half is exactly 0x80000000
+    assert off + 2 ** 30 <= big.numel()
+
+    def carve(nfloats):
+        nonlocal off
+        t = big[off:off + 4 * nfloats].view(torch.float32)
+        assert (t.data_ptr() & 0xffffffff) >= 0x80000000 and t.data_ptr() % 256 == 0
+        off += (4 * nfloats + 255) // 256 * 256
+        return t
+
+    rs = np.random.RandomState(11)
+    hseq = _dev(rs.standard_normal((L, T, B, H)))
+    dG = _dev(rs.standard_normal((L, T, B, G)))
+    hpl, gpl = carve(L * T * B * H * 3 // 2), carve(L * T * B * G * 3 // 2)
+    dWh = [carve(G * H).zero_() for _ in range(L)]
+    dWx = [torch.zeros(G, E, device="cuda"), carve(G * H).zero_()]
+    dbias = [torch.zeros(G, device="cuda"), carve(G).zero_()]
+    x_tb = torch.zeros(T, B, dtype=torch.int32, device="cuda")
+    emb, wx0 = _dev(rs.standard_normal((V, E))), _dev(rs.standard_normal((G, E)))
+    dtab, onehot, demb = torch.zeros(V, G, device="cuda"), torch.zeros(T * B, V, device="cuda"), torch.zeros(V, E, device="cuda")
+    pwx, _a = _lib.ptr_array(dWx); pwh, _b = _lib.ptr_array(dWh); pbs, _c = _lib.ptr_array(dbias)
+    caps = (C.c_long * 4)(hpl.numel(), gpl.numel(), 0, 0)
+    # parts: per-layer GEMMs | exact-f32 table path (unused) | planes | "the rings are scratch: split dG / h here first"
+    rc = lib.arcvae_enc_lstm_wgrad(_lib.ptr(x_tb), _lib.ptr(emb), _lib.ptr(wx0), _lib.ptr(hseq), _lib.ptr(dG), _lib.ptr(dtab),
+                                   _lib.ptr(onehot), _lib.ptr(demb), pwx, pwh, pbs, B, T, V, E, H, L, 0, T, 0, 0,
+                                   1 | 16 | 2048 | 4096, _lib.ptr(hpl), _lib.ptr(gpl), caps, _lib.stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    g64, h64 = dG.double().cpu().numpy(), hseq.double().cpu().numpy()
+    for l in range(L):                                            # dWh_l = sum_t dG_l[t]^T h_l[t-1]
+        assert rel_err(dWh[l].cpu().numpy().reshape(G, H), sum(g64[l, t].T @ h64[l, t - 1] for t in range(1, T))) < TOL
+    assert rel_err(dWx[1].cpu().numpy().reshape(G, H), sum(g64[1, t].T @ h64[0, t] for t in range(T))) < TOL
+    assert rel_err(dbias[1].cpu().numpy(), g64[1].sum((0, 1))) < TOL   # the bias rider's pointer too
+    del big
