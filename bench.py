@@ -395,9 +395,29 @@ def main(argv=None):
         ops = dp_.ops
         if not getattr(ops, "gated", False):
             return "event form: decoder bucket on a comm stream beside the sweep, encoder bucket after it"
+        if getattr(ops, "early", True) and getattr(ops, "heads_early", False):
+            return ("gated form: decoder bucket, then the encoder heads' bucket (behind a device-side gate) reduced early on side through "
+                    "a second communicator; the LSTM layers + embedding bucket on main after the join")
         return ("gated form: decoder bucket reduced early on side through a second communicator, encoder bucket on main after the join"
                 if getattr(ops, "early", True) else
                 "gated form, ARCVAE_DP_EARLY_REDUCE=0: the whole gradient bucket reduced on main after the join")
+
+    def comm_probe(dp_, one_step_, n_inputs, n=12):
+        """Device-side stamps around every collective over n extra (untimed) steps: medians by bucket and `exposed_comm_us` (the
+        main-stream collectives: on the step's chain).  Unmeasured on more than one GPU until the driver's multi-GPU run; at
+        world size 1 (--force-dp) the figures are RCCL's launch + single-rank kernel cost."""
+        if dp_ is None:
+            return None
+        torch.cuda.synchronize()
+        dp_.timing = {}
+        for i in range(n):
+            one_step_(i % n_inputs)
+        torch.cuda.synchronize()
+        rep = dp_.comm_report()
+        dp_.timing = None
+        rep["note"] = ("HIP events around each collective on the stream it is issued on, median over %d untimed steps after the timed "
+                       "region; main-stream time is exposed on the chain, side-stream time runs beside the sweeps" % n)
+        return rep
 
     def healthy(eng_) -> str:
         """'' when every device-side gate opened in order and no persistent sweep gave up, on EVERY rank."""
@@ -455,6 +475,7 @@ def main(argv=None):
     log("timing")
     dt, host_enq = timed(one_step, args.warmup, args.steps)
     scal = ws.scalars.cpu().numpy()
+    comm = comm_probe(dp, one_step, total) if use_dp else None
     # a device-side gate or a persistent sweep that gave up waiting would mean the streams lost their order: no number
     # then -- and every rank leaves together (a lone exit would park the others in a barrier)
     why = healthy(eng)
@@ -489,6 +510,8 @@ def main(argv=None):
             "step_tflops_executed": f_exec / (dt / args.steps) / 1e12,
             "step_executed_frac_of_f32_mfma_peak": f_exec / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
         }
+        if comm is not None:
+            out["comm"] = comm
         log(f"timed: {ms:.3f} ms/step, {seqs:.0f} seq/s (host enqueue {1e3 * host_enq / args.steps:.3f} ms/step)")
     if rank == 0 and not args.no_roofline:
         nb = T + 2 * (L - 1)
@@ -521,6 +544,7 @@ def main(argv=None):
             why = healthy(eng2)
             if not why:
                 dt2, _ = timed(step2, args.strong_warmup, args.strong_steps)
+                comm2 = comm_probe(dp2, step2, stotal) if use_dp else None
                 why = healthy(eng2)
             if why:
                 strong = {"global_batch": G2, "rows_per_gpu": rows, "skipped": why}
@@ -536,6 +560,8 @@ def main(argv=None):
                           "dp_form": dp_form(dp2), "gates_ok_all_ranks": True,
                           "bptt_kernel": ("lstm_bwd_persist_rs_kernel" if E.bptt_reduce_scatter_ok(ws2, dims)
                                           else "per-step launches (lstm_bwd_step*/tile kernels)")}
+                if comm2 is not None:
+                    strong["comm"] = comm2
                 if rank == 0 and not args.no_roofline:
                     strong["roofline"] = roofline_probe(eng2, ws2, torch)       # this leg's own dominant kernel, live
                 log(f"strong leg: global batch {G2} = {rows} rows/GPU x {world}: {strong['ms_per_step']:.3f} ms/step, "

@@ -83,11 +83,36 @@ class DataParallelStep:
         warm = getattr(ops, "warm_up", None)
         if warm is not None and self.early_group is not None:
             warm(self.early_group)                      # set the second communicator up before any gate can wait behind it
+        # Instrument for the first multi-GPU runs (bench.py): `timing = {}` switches on a pair of device events around every
+        # collective, recorded on the stream it is issued on -- the time that stream spends between "everything before the
+        # collective is done" and "the collective is done", i.e. transfer + waiting for the slowest peer.  On MAIN (stats seam,
+        # late bucket) that time is on the step's critical chain: exposed communication.  Off by default (None): no events.
+        self.timing = None
 
-    def _all_reduce(self, t: Optional[torch.Tensor], group=None) -> None:
+    def _all_reduce(self, t: Optional[torch.Tensor], group=None, tag: Optional[str] = None) -> None:
         if t is None or (self.world == 1 and not self.force):
             return
+        if self.timing is not None and tag is not None and t.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group if group is not None else self.group)
+            e1.record()
+            self.timing.setdefault(tag, []).append((e0, e1, int(t.numel()) * t.element_size()))
+            return
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group if group is not None else self.group)
+
+    def comm_report(self) -> dict:
+        """Median device time (us) of every collective of the instrumented steps (after a synchronize), by bucket, with the
+        message size and the stream it was issued on; `exposed_comm_us` = the main-stream ones (stats seam + late bucket)."""
+        rep, exposed = {}, 0.0
+        for tag, evs in (self.timing or {}).items():
+            us = sorted(1e3 * a.elapsed_time(b) for a, b, _ in evs)
+            where = "side (beside the sweeps)" if tag in ("ce_sum", "dec_bucket", "heads_bucket") else "main (on the chain)"
+            rep[tag] = {"us_median": us[len(us) // 2], "us_max": us[-1], "bytes": evs[0][2], "issued_on": where, "n": len(us)}
+            if where.startswith("main"):
+                exposed += us[len(us) // 2]
+        rep["exposed_comm_us"] = exposed
+        return rep
 
     def step(self) -> None:
         ops = self.ops
@@ -96,23 +121,26 @@ class DataParallelStep:
         ops.forward_local()
         with ops.early_context():                       # decoder-side results: independent of the stats seam (Q2), so
             ops.recon_local()                           # issued first -- they run beside the encoder's sweeps
-            self._all_reduce(ops.recon_stat, self.early_group)
+            self._all_reduce(ops.recon_stat, self.early_group, "ce_sum")
             for g in ops.early_buckets():
-                self._all_reduce(g, self.early_group)
+                self._all_reduce(g, self.early_group, "dec_bucket")
             done = getattr(ops, "early_done", None)
             if done is not None:
                 done()
             if seam_early:                              # the encoder heads' gradients: ready right behind the seam; the ops
                 for g in seam():                        # put a device-side gate in front of the reduce (SURVEY 8e bucket order)
-                    self._all_reduce(g, self.early_group)
-        self._all_reduce(ops.stats)                     # forward seam (critical path, 2Z+3 floats)
+                    self._all_reduce(g, self.early_group, "heads_bucket")
+        self._all_reduce(ops.stats, None, "stats")      # forward seam (critical path, 2Z+3 floats)
         ops.backward_local()
-        if seam is not None and not seam_early:         # host-ordered forms (CPU doubles, event form): behind the backward
-            with ops.early_context():
+        if seam is not None and not seam_early:         # host-ordered forms (CPU doubles, event form, a driver's first step):
+            with ops.early_context():                   # behind the backward's enqueue
                 for g in seam():
-                    self._all_reduce(g, self.early_group)
+                    self._all_reduce(g, self.early_group, "heads_bucket")
+            join = getattr(ops, "seam_join", None)
+            if join is not None:
+                join()                                  # the late buckets' stream follows the seam buckets' reduce
         for g in ops.late_buckets():
-            self._all_reduce(g)
+            self._all_reduce(g, None, "enc_bucket")
         ops.apply_update()
 
 
@@ -167,8 +195,13 @@ class EngineOps:
         # every CU; this switch is the fallback if that turns out to cost more than the overlap gains.
         self.early = os.environ.get("ARCVAE_DP_EARLY_REDUCE", "1") != "0"
         # the encoder heads' gradients reduced early as well (gated + early form only): SURVEY 8e's second bucket
-        self.heads_early = self.gated and self.early and os.environ.get("ARCVAE_DP_HEADS_EARLY", "1") != "0"
-        self.seam_issue_early = True     # (DataParallelStep: seam buckets are ordered by a device-side gate, issue them on side now)
+        # (only where a collective is ENQUEUED, i.e. RCCL: the reduce sits on side behind a device-side gate that opens once aux has
+        # formed those gradients -- which the host enqueues AFTER this reduce.  A host-blocking backend -- gloo carrying device
+        # tensors, the one-GPU rehearsal -- would wait in the reduce for a gate whose signal it has not enqueued yet: it keeps
+        # round 3's order, the whole encoder bucket on main after the join)
+        self.heads_early = (self.gated and self.early and os.environ.get("ARCVAE_DP_HEADS_EARLY", "1") != "0"
+                            and dist.is_initialized() and dist.get_backend(group) == "nccl")
+        self._steps = 0                  # steps this driver has enqueued (the first one records the segments: seam_issue_early)
         if self.gated:
             self._make_bucket()
             self.recon_stat = None
@@ -297,6 +330,15 @@ class EngineOps:
         if self.gated and self.early:
             self._dec_adam_gated()                   # decoder gradients are GLOBAL: its Adam update rides on side too
 
+    @property
+    def seam_issue_early(self) -> bool:
+        """DataParallelStep: issue the seam (heads) bucket with the early buckets, AHEAD of backward_local's enqueue -- a device-side
+        gate orders it.  Not in a driver's FIRST step: that step records the segments, and a capture begins with a device-wide
+        synchronize (torch.cuda.graph) -- with the gate already pending on side and its signal (aux's heads_wgrad, enqueued by
+        backward_local) not enqueued yet, the host would sit there until the gate's bounded spin expired (seen: 15 s, ERR = 1).
+        The first step therefore issues the bucket behind the backward (host order), like the CPU doubles do."""
+        return self.heads_early and self._steps > 0
+
     def seam_buckets(self) -> List[torch.Tensor]:
         """The encoder heads' gradients, on SIDE behind the decoder's bucket: a device-side gate (word HG, raised by aux once
         heads_wgrad of THIS step has run: engine._encoder_backward_gated) orders the reduce behind them."""
@@ -305,10 +347,18 @@ class EngineOps:
         from .engine import EncoderBackwardPlan
         g = self.eng.gates
         # side's ticket counter NS is advanced by the LAST gate of a step on side: with a single-chunk sweep that is the decoder
-        # segment's own gate (in front of this one: offset 0), else the tail chunk's (behind it: offset 1)
-        off = 0 if len(EncoderBackwardPlan(self.eng.enc, self.ws, self.eng.d).chunks) < 2 else 1
-        self.run("dp_heads_gate", lambda: g.wait(g.HG, g.NS, 1, off), torch.cuda.current_stream())
+        # segment's own gate (in front of this one: offset 0), else the tail chunk's (behind it: offset 1).  Issued late (a
+        # driver's first step) it follows the tail chunk's gate too: offset 0.
+        early = self.seam_issue_early
+        off = 1 if (early and len(EncoderBackwardPlan(self.eng.enc, self.ws, self.eng.d).chunks) >= 2) else 0
+        # (a plain launch, NOT a recorded segment: one kernel, and a segment's first use synchronises its stream)
+        g.wait(g.HG, g.NS, 1, off)
         return [self.bucket_heads]
+
+    def seam_join(self) -> None:
+        """First step only (seam bucket issued late, behind side's report on R): main follows side's reduce by an event."""
+        if self.heads_early:
+            torch.cuda.current_stream().wait_stream(self.eng.side)
 
     def late_buckets(self) -> List[torch.Tensor]:
         if self.gated:
@@ -319,6 +369,7 @@ class EngineOps:
         return [self.eng.enc.grad]
 
     def apply_update(self) -> None:
+        self._steps += 1
         if self.gated:
             self._finish_gated()
             return

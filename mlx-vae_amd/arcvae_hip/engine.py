@@ -772,9 +772,14 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
             if last:
                 g.signal(g.R, 1)
 
+        # Host order: aux's segment of a chunk BEFORE side's.  aux waits for main's signals only; side may also wait for aux's (Q; under
+        # data parallelism HG, "the heads' gradients are formed", in front of the early heads-bucket reduce) -- and a segment's FIRST
+        # use runs eagerly and then synchronises its stream for the capture (SegmentRunner), so whatever could release a gate of that
+        # stream has to be enqueued by then (round 4: with side first, the first data-parallel step sat in side.synchronize() behind
+        # the HG gate until its bounded spin expired).  tests/test_gate_protocol.py replays this first step too.
+        run(f"aux{c}", aux_seg, aux)
         if table_on_side or (last and tail_on_side):
             run(f"aux2_{c}", side_seg, aux2)
-        run(f"aux{c}", aux_seg, aux)
     if aux2 is not None and not tail_on_side:
         main.wait_stream(aux2)  # single-chunk sweeps (T <= 3): side only ran the decoder and reported nothing
     # The caller's next main-stream segment must BEGIN with `Gates.join(g)`: main polls R there (a gate reacts within

@@ -155,10 +155,10 @@ class _CountingGroupCalls:
         self.step, self.calls = step, []
         inner = step._all_reduce
 
-        def spy(t, group=None):
+        def spy(t, group=None, tag=None):
             if t is not None:
-                self.calls.append(("early" if group is step.early_group else "main", int(t.numel())))
-            inner(t, group)
+                self.calls.append(("early" if group is step.early_group else "main", int(t.numel()), tag))
+            inner(t, group, tag)
         step._all_reduce = spy
 
 
@@ -196,8 +196,8 @@ def _worker(rank, world, port, ret, sub_ranks=None):
     # bucket follows the backward's enqueue (on the GPU: a device-side gate, issued with the early buckets), the LSTM bucket last
     assert ops.order == ["forward_local", "recon_local", "early_done", "backward_local", "seam_buckets", "late_buckets"], ops.order
     # which communicator carried what, in issue order: {CE sum, decoder, heads} early; {stats, LSTM + embedding} main
-    assert spy.calls == [("early", 1), ("early", ops.dec_grad.numel()), ("main", 2 * cfg.Z + 3),
-                         ("early", ops.heads_grad.numel()), ("main", ops.lstm_grad.numel())], spy.calls
+    assert spy.calls == [("early", 1, "ce_sum"), ("early", ops.dec_grad.numel(), "dec_bucket"), ("main", 2 * cfg.Z + 3, "stats"),
+                         ("early", ops.heads_grad.numel(), "heads_bucket"), ("main", ops.lstm_grad.numel(), "enc_bucket")], spy.calls
     assert 0 < ops.heads_grad.numel() < ops.lstm_grad.numel()
     out = {k: v.detach().numpy() for k, v in ops.p.items()}
     if me == 0:

@@ -165,6 +165,13 @@ def test_dp_driver_single_rank_rccl():
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     a, b = outs
     assert a["n_gpus"] == 1 and abs(a["elbo"]["total"] - b["elbo"]["total"]) < 1e-4 * max(1.0, abs(b["elbo"]["total"]))
+    # round 4: SURVEY 8e's bucket order under RCCL -- decoder, then the encoder heads' bucket behind its device-side gate on side, the
+    # LSTM bucket on main -- ran with every gate opening in order, and the per-collective stamps are in the line
+    assert "heads" in a["config"]["dp_form"] and a["config"]["gates_ok_all_ranks"] is True, a["config"]
+    comm = a["comm"]
+    assert {"dec_bucket", "heads_bucket", "stats", "enc_bucket", "exposed_comm_us"} <= set(comm), comm   # (gated form: the CE sum rides in the decoder's bucket)
+    assert comm["heads_bucket"]["bytes"] < comm["enc_bucket"]["bytes"] < comm["dec_bucket"]["bytes"] + comm["enc_bucket"]["bytes"]
+    assert 0.0 < comm["exposed_comm_us"] < 2000.0
 
 
 @pytest.mark.parametrize("H,L,B,T,C", [(512, 4, 24, 10, 1), (128, 1, 33, 9, 2), (192, 2, 16, 8, 1), (320, 3, 7, 6, 4)])

@@ -65,7 +65,7 @@ class _Plan:
             self.g.note("wgrad", c, parts & 15)     # bits 4, 5, 8 choose kernels / workspaces / the zero fill, not pieces
 
 
-def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
+def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False, first_step=False):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = _Recorder()
@@ -75,9 +75,12 @@ def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
     plan = _Plan(g, T, L, fractions, persistent)
     nc = len(plan.chunks)
 
+    host = []                                    # host enqueue order: (stream, ops enqueued on it so far, first use synchronises?)
+
     def run(key, fn, stream):
         g.cur = stream
         fn()
+        host.append((stream, len(g.ops[stream]), True))     # a recorded segment: eager + stream.synchronize() on its first use
 
     def prologue():                              # the forward sweep raises signal #1 when it starts
         g.note("signal", E.Gates.P, 1)
@@ -90,16 +93,67 @@ def _record_step(T, L, fractions, persistent, env, monkeypatch, dp=False):
     if dp:                                       # dp.py: forward and decoder are enqueued on their own, the backward after them
         g.cur = main
         prologue()
+        host.append((main, len(g.ops[main]), True))          # gated:enc_fwd
         decoder_after_main()
+        host.append((side, len(g.ops[side]), True))          # gated:dec_all
         g.cur = side                             # EngineOps (gated): CE sum, all-reduce of [dec.grad | CE sum] and the decoder's
         g.note("dec_reduce")                     # Adam are side's NEXT operations (stream order: no gate, no event)
+        # round 4: behind them, still on side, the encoder HEADS' bucket -- gated on "aux has formed those gradients" (word HG;
+        # dp.EngineOps.seam_buckets: offset 0 when the decoder's own gate already advanced side's ticket, i.e. single-chunk sweeps).
+        # A driver's FIRST step (it records the segments) issues it behind the backward instead: EngineOps.seam_issue_early.
+        if not first_step:
+            g.wait(E.Gates.HG, E.Gates.NS, 1, 0 if nc < 2 else 1)
+            g.note("heads_reduce")
+        host.append((side, len(g.ops[side]), False))         # plain launches and enqueued collectives: the host does not wait
         E._encoder_backward_gated(plan, None, aux, side, run, None, None, g)
+        if first_step:
+            g.cur = side
+            g.wait(E.Gates.HG, E.Gates.NS, 1, 0)
+            g.note("heads_reduce")
+            host.append((side, len(g.ops[side]), False))
     else:
         E._encoder_backward_gated(plan, None, aux, side, run, prologue, decoder_after_main, g)
     g.cur = main
     if nc >= 2:
         g.join()                                 # enqueue_finish / _join_gated
+    host.append((main, len(g.ops[main]), True))
+    _record_step.host = host
     return g.ops, (main, side, aux), nc
+
+
+def _replay_first_step(ops, streams, host):
+    """The FIRST step of a driver: every recorded segment runs eagerly, the host then waits for that segment's stream to drain
+    (SegmentRunner: stream.synchronize()) and the capture that follows begins with a DEVICE-WIDE synchronize (torch.cuda.graph) --
+    so every gate pending on ANY stream at that point must be releasable by what the host has enqueued so far.  Replays the
+    host's enqueue order with that rule; returns normally iff the host never blocks for good."""
+    flags, pc, limit = {}, {s: 0 for s in streams}, {s: 0 for s in streams}
+
+    def advance():
+        moved = True
+        while moved:
+            moved = False
+            for s in streams:
+                while pc[s] < limit[s]:
+                    op = ops[s][pc[s]]
+                    if op[0] == "wait":
+                        _, w, cnt, stride, offset, adv = op
+                        if flags.get(w, 0) < flags.get(cnt, 0) * stride + offset:
+                            break
+                        if adv:
+                            flags[cnt] = flags.get(cnt, 0) + 1
+                    elif op[0] == "signal":
+                        flags[op[1]] = flags.get(op[1], 0) + op[2]
+                    pc[s] += 1
+                    moved = True
+
+    for s, n, sync in host:
+        limit[s] = max(limit[s], n)
+        advance()
+        if sync:
+            for q in streams:
+                assert pc[q] == limit[q], (f"first step: the host synchronises the device at a segment of {s.name} while {q.name} sits "
+                                           f"behind {ops[q][pc[q]]} -- nothing enqueued so far releases it")
+    assert all(pc[s] == len(ops[s]) for s in streams)
 
 
 def _replay(ops, streams, steps):
@@ -110,6 +164,8 @@ def _replay(ops, streams, steps):
     per = {s: len(ops[s]) for s in streams}
     sweeps_done = set()                          # (step, chunk)
     heads1_done = set()                          # steps whose dcomb chain (heads phase 1) has run
+    heads2_done = set()                          # steps whose heads' parameter gradients (phase 2, on aux) are formed
+    heads_reduced_early = []
     advanced = {}
     reduced_early = []
     nc_last = max([op[1] for op in ops[main] if op[0] == "sweep_done"], default=0)
@@ -139,6 +195,13 @@ def _replay(ops, streams, steps):
                         heads1_done.add(step)
                     else:                        # the heads' parameter gradients read what the dcomb chain of THIS step wrote
                         assert step in heads1_done, f"{s.name}: heads' parameter gradients before the dcomb chain (step {step})"
+                        heads2_done.add(step)
+                elif op[0] == "heads_reduce":        # dp: the heads' bucket is reduced once THIS step's gradients are formed ...
+                    assert step in heads2_done, f"{s.name}: heads' bucket reduced before its gradients were formed (step {step})"
+                    # ... and before main has JOINED this step (its reduce must be inside what the join covers: side reports on R
+                    # behind it in stream order).  (In this model a chunk is one operation and the heads' gradients are formed behind
+                    # chunk 0, so "before the sweep's last chunk is done" cannot be asked here as it is of the decoder's bucket.)
+                    heads_reduced_early.append(flags.get(E.Gates.NM, 0) <= step)
                 elif op[0] == "wgrad":
                     assert (step, op[1]) in sweeps_done, f"{s.name}: gradients of chunk {op[1]} before its sweep (step {step})"
                 elif op[0] == "dec_reduce":          # the decoder's bucket is reduced beside the sweep: before its LAST chunk is done
@@ -147,6 +210,7 @@ def _replay(ops, streams, steps):
                 moved = True
         assert moved, "deadlock: " + ", ".join(f"{s.name} at {prog[s][pc[s]] if pc[s] < len(prog[s]) else 'end'}" for s in streams)
     _replay.reduced_early = reduced_early
+    _replay.heads_reduced_early = heads_reduced_early
     return flags, advanced
 
 
@@ -161,7 +225,13 @@ def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persis
     # tables_on_main: every chunk folds its own token table, main forms the last chunk's behind its own sweep (round 2)
     monkeypatch.setattr(E, "_tables_on_main", lambda plan, ws: tables_on_main)
     ops, streams, nc = _record_step(T, L, fractions, persistent, env, monkeypatch, dp)
+    host_early = _record_step.host
     assert nc >= 2
+    ops1, streams1, _ = _record_step(T, L, fractions, persistent, env, monkeypatch, dp, first_step=True)
+    _replay_first_step(ops1, streams1, _record_step.host)      # the eager, synchronising first step does not block for good
+    if dp:   # ... and it would, had the first step put the heads' gate on side ahead of the backward's enqueue (seen on the GPU: 15 s, ERR)
+        with pytest.raises(AssertionError, match="first step"):
+            _replay_first_step(ops, streams, host_early)
     steps = 5
     flags, advanced = _replay(ops, streams, steps)
     G = E.Gates
@@ -169,8 +239,11 @@ def test_gated_backward_never_blocks_and_keeps_its_order(T, L, fractions, persis
     assert flags[G.R] == 2 * steps and flags[G.NM] == steps    # aux and side report once each; main joins once
     assert flags[G.NS] == steps and flags[G.NA] == steps       # every waiter's ticket counter: once per step
     assert flags[G.D] == steps                                 # decoder segments reported
+    assert flags[G.HG] == steps                                # aux raised "heads' gradients formed" once per step
     if dp:   # the decoder's all-reduce is issued (and can run) before the BPTT sweep has finished, in every step
         assert len(_replay.reduced_early) == steps and all(_replay.reduced_early)
+        # ... the encoder heads' (second bucket) never before aux has formed those gradients, always inside the join
+        assert len(_replay.heads_reduced_early) == steps and all(_replay.heads_reduced_early)
     assert all(v == 1 for v in advanced.values())
     # every chunk's gradient pieces are formed exactly once per step, between the streams
     done = {}

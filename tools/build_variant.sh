@@ -6,7 +6,7 @@ NAME=$1; FLAGS=$2
 cd "$(dirname "$0")/../mlx-vae_amd/csrc"
 mkdir -p ../../ab_libs build/$NAME
 for f in gemm misc lstm decoder latent; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $FLAGS -c $f.hip -o build/$NAME/$f.o &
+  /opt/rocm/bin/hipcc -I../../include -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function $FLAGS -c $f.hip -o build/$NAME/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../ab_libs/libarcvae_$NAME.so build/$NAME/*.o
