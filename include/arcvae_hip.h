@@ -358,6 +358,13 @@ int arcvae_adam_update(float* params, const float* grads, float* m, float* v, lo
                        double beta1, double beta2, double eps, const unsigned* guard_a, const unsigned* guard_b,
                        arcvae_stream_t stream);
 
+/* arcvae_recon_finalize + arcvae_adam_update as ONE launch (the exposed tail of the single-process step, trainer.py:320-366):
+ * block 0 sums the CE rows into stats[2Z+3] and writes the recon / total scalars (NaN and scalars[15] = 1 when a guard word is set),
+ * then the update as above (skipped on a guard). */
+int arcvae_adam_update_finalize(float* params, const float* grads, float* m, float* v, long n, double lr, double beta1,
+                                double beta2, double eps, const unsigned* guard_a, const unsigned* guard_b,
+                                const float* rowloss, int B, float* stats, float* scalars, int Z, int T, arcvae_stream_t stream);
+
 /* ---- small helpers ---------------------------------------------------------------------------------- */
 int arcvae_colsum_accum(const float* X, int rows, int cols, int ld, float* out, float scale,
                         arcvae_stream_t stream);

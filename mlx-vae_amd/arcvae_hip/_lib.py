@@ -86,6 +86,7 @@ SIGNATURES = {
     "arcvae_ce_rows": [_vp, _vp, _vp, _l, _i, _vp],
     "arcvae_sum": [_vp, _l, _vp, _f, _vp],
     "arcvae_adam_update": [_vp, _vp, _vp, _vp, _l, _d, _d, _d, _d, _vp, _vp, _vp],
+    "arcvae_adam_update_finalize": [_vp, _vp, _vp, _vp, _l, _d, _d, _d, _d, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp],
     "arcvae_colsum_accum": [_vp, _i, _i, _i, _vp, _f, _vp],
     "arcvae_segsum_rows_accum": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "arcvae_transpose_batched": [_pp, _pp, _ip, _ip, _i, _vp],

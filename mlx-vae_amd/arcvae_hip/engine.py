@@ -430,13 +430,33 @@ class SegmentRunner:
         self.capture = capture
         self._g: Dict[str, object] = {}
         self._cap_stream: Optional[torch.cuda.Stream] = None  # capture may not happen on the default stream
+        self.steps = 0          # single-process steps enqueued through this runner (StepEngine._enqueue_step)
 
-    def __call__(self, key: str, fn, stream: torch.cuda.Stream) -> None:
+    def __call__(self, key: str, fn, stream: torch.cuda.Stream, eager_first: bool = True) -> None:
+        """eager_first=False: the segment's first use is capture + replay WITHOUT the eager run (and its stream.synchronize())
+        -- for a segment that contains a gate other streams release only later in the same step (the merged main + finish
+        segment: its join would hold the host in synchronize() until the gate expired); every launch in it must have run
+        before (lazy kernel attributes are set)."""
         with torch.cuda.stream(stream):
             if not self.capture:
                 fn()
                 return
             g = self._g.get(key)
+            if g is None and not eager_first:
+                try:
+                    if self._cap_stream is None:
+                        self._cap_stream = torch.cuda.Stream(device=stream.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode="thread_local"):
+                        fn()
+                    self._g[key] = g
+                    g.replay()
+                except Exception as exc:
+                    print(f"[arcvae_hip] graph capture of segment {key!r} failed ({exc}); running it eagerly")
+                    torch.cuda.synchronize()
+                    self._g[key] = False
+                    fn()
+                return
             if g is None:
                 fn()  # first step runs eagerly (its results are this step's results) ...
                 stream.synchronize()
@@ -617,7 +637,7 @@ class EncoderBackwardPlan:
 
 def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional[torch.cuda.Stream] = None,
                      run=_inline, prologue=None, after_first=None, aux2: Optional[torch.cuda.Stream] = None,
-                     gates: Optional[Gates] = None) -> None:
+                     gates: Optional[Gates] = None, epilogue=None) -> None:
     """Backward of heads + LSTM stack on (current stream, aux).  `prologue` (optional) is enqueued at the head
     of the first main-stream segment (used to fuse encoder forward + loss into it); `after_first` (optional) is
     called on the host right after that first segment has been enqueued (the decoder is enqueued there: early
@@ -637,7 +657,7 @@ def encoder_backward(enc: ParamStore, ws: Workspace, d: ModelDims, aux: Optional
             after_first()
         return
     if gates is not None:
-        _encoder_backward_gated(plan, ws, aux, aux2, run, prologue, after_first, gates)
+        _encoder_backward_gated(plan, ws, aux, aux2, run, prologue, after_first, gates, epilogue)
         return
     for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
         def main_seg(c=c, s0=s0, s1=s1):
@@ -679,7 +699,7 @@ def _tables_on_main(plan, ws) -> bool:
 
 
 def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2, run, prologue, after_first,
-                            g: Gates) -> None:
+                            g: Gates, epilogue=None) -> None:
     """encoder_backward with device-side gates instead of event waits (class Gates).  Main's signals of a step:
     #1 inputs ready (enqueued by the caller), #(2+c) after sweep chunk c, the last chunk topping P up to a multiple
     of STRIDE.  aux: chunk c runs behind signal #(2+c); it signals Q once (after its last-but-one chunk).  side:
@@ -732,8 +752,16 @@ def _encoder_backward_gated(plan: EncoderBackwardPlan, ws: Workspace, aux, aux2,
         if own_tables:
             _s0, _s1, t_lo_l, t_hi_l, _f, _l = plan.chunks[-1]
             plan.wgrad(t_lo_l, t_hi_l, True, True, 2 | 32 | pre_zeroed(), table=getattr(ws, "dtable1", None))
+        if epilogue is not None:
+            # the step's finish (join of aux / side, loss finalize, the encoder's Adam) as the END of this segment: one graph
+            # launch less on main (~9 us of seam between two graph launches in the exposed tail: profiles/r04_timeline_*.txt)
+            epilogue()
 
-    run("main", main_seg, main)
+    if epilogue is not None:
+        # (its join is released by segments the host enqueues below: never run eagerly + synchronised -- SegmentRunner.eager_first)
+        run("main+finish", main_seg, main, eager_first=False)
+    else:
+        run("main", main_seg, main)
     if after_first:
         after_first()
     for c, (s0, s1, t_lo, t_hi, first, last) in enumerate(plan.chunks):
@@ -1096,7 +1124,7 @@ class StepEngine:
         self.ev_enc_fwd.record(torch.cuda.current_stream())
 
     def enqueue_backward(self, ws: Workspace, run=_inline, fuse_forward: bool = False, after_first=None,
-                         gates: Optional[Gates] = None, start_signal=None) -> None:
+                         gates: Optional[Gates] = None, start_signal=None, epilogue=None) -> None:
         """`stats[:2Z+3]` holds GLOBAL sums (or, with fuse_forward, will: single process): latent loss scalars
         and gradients, then the encoder backward.  Does NOT wait for the decoder."""
         fb = float(self.hyper_host["free_bits"])
@@ -1110,7 +1138,7 @@ class StepEngine:
         # fourth stream, `side` owns a hardware queue of its own (HIP maps streams onto 4 queues), so the two
         # halves really run side by side
         encoder_backward(self.enc, ws, self.d, aux=self.aux, run=run, prologue=prologue, after_first=after_first,
-                         aux2=self.side, gates=gates)
+                         aux2=self.side, gates=gates, epilogue=epilogue)
 
     def enqueue_recon(self, ws: Workspace, run=_inline) -> None:
         """stats[2Z+3] = sum of this process's CE row sums (after the decoder's TF walk)."""
@@ -1128,10 +1156,24 @@ class StepEngine:
         if join_side:
             main.wait_stream(self.side)
 
+        fin = self._finish_ops(ws, lr, update, with_recon, dec_adam, gates)
+        run(("finish" if update else "finish_noupdate") + ("_r" if with_recon else ""), fin, main)
+
+    def _finish_ops(self, ws: Workspace, lr: float, update: bool, with_recon: bool, dec_adam: bool, gates: Optional[Gates]):
+        """The launches of a step's finish as a closure (its own segment, or the end of the main segment: _enqueue_step)."""
         def fin():
             if gates is not None:
                 gates.join()
             ga, gb = self.guards(ws)
+            if with_recon and update:
+                # CE sum + recon / total scalars ride in block 0 of the encoder's Adam launch (round 4: one launch less in the tail)
+                if dec_adam:
+                    adam_update(self.dec, lr, guards=(ga, gb))
+                st = self.enc
+                call("arcvae_adam_update_finalize", ptr(st.flat), ptr(st.grad), ptr(st.adam_m), ptr(st.adam_v),
+                     C.c_long(st.numel_padded), float(lr), 0.9, 0.999, 1e-8, ga, gb, ptr(ws.rowloss), ws.B, ptr(ws.stats),
+                     ptr(ws.scalars), self.d.Z, ws.T, stream_ptr())
+                return
             if with_recon:   # CE sum + recon/total scalars in one launch
                 call("arcvae_recon_finalize", ptr(ws.rowloss), ws.B, ptr(ws.stats), ptr(ws.scalars), self.d.Z, ws.T,
                      ga, gb, stream_ptr())
@@ -1141,8 +1183,7 @@ class StepEngine:
                 if dec_adam:
                     adam_update(self.dec, lr, guards=(ga, gb))
                 adam_update(self.enc, lr, guards=(ga, gb))
-
-        run(("finish" if update else "finish_noupdate") + ("_r" if with_recon else ""), fin, main)
+        return fin
 
     def _enqueue_step(self, ws: Workspace, lr: float, global_rows: int, update: bool, run=_inline) -> None:
         """Single-process step.  Host enqueue order: the decoder segment (one short graph launch; it overlaps the
@@ -1157,6 +1198,12 @@ class StepEngine:
             def grun(key, fn, stream, _run=run):             # gated segments are recorded under their own names
                 _run(f"gated:{key}", fn, stream)
 
+            def grun_e(key, fn, stream, eager_first=True, _run=run):
+                if eager_first:
+                    _run(f"gated:{key}", fn, stream)
+                else:
+                    _run(f"gated:{key}", fn, stream, eager_first=False)
+
             # Signal #1 ("inputs ready": releases the decoder on side) is raised by the forward sweep when it starts.
             # The main segment -- encoder forward + loss + dcomb + the whole BPTT chain, no seam in it -- is enqueued
             # first, the decoder right behind it (in the first, eager step the decoder's gate could otherwise be
@@ -1167,6 +1214,19 @@ class StepEngine:
                 self.enqueue_decoder(ws, global_rows, grun, wait_current=False, split_events=False, gate=(g, nc < 2),
                                      adam_lr=lr if update else None)
 
+            # From a runner's second step on, the finish rides at the end of the main segment (ARCVAE_MERGE_FINISH=0: never).  Not
+            # in its first step -- that one runs every segment eagerly and synchronises, and the finish begins with a join that aux
+            # and side release only later -- and not for single-chunk sweeps (their join is an event wait between the segments).
+            steps_done = getattr(run, "steps", 0)
+            if hasattr(run, "steps"):
+                run.steps += 1
+            merged = (nc >= 2 and steps_done >= 1 and getattr(run, "capture", False)
+                      and not fused_wgrad_ok(ws, self.d) and os.environ.get("ARCVAE_MERGE_FINISH", "1") != "0")
+            if merged:
+                fin = self._finish_ops(ws, lr, update, True, False, g)
+                self.enqueue_backward(ws, grun_e, gates=g, fuse_forward=True, after_first=dec_after_main,
+                                      start_signal=g.word(g.P), epilogue=fin)
+                return
             self.enqueue_backward(ws, grun, gates=g, fuse_forward=True, after_first=dec_after_main,
                                   start_signal=g.word(g.P))
             self.enqueue_finish(ws, lr, update, grun, with_recon=True, dec_adam=False, join_side=False, gates=g)

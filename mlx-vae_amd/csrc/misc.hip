@@ -323,14 +323,41 @@ __global__ void transpose_tokens_kernel(const int32_t* __restrict__ src, int32_t
 // HBM-bound: 4 streams read + 3 written = 28 B/param.
 // guard_a / guard_b (optional): device error words (an expired gate, a persistent sweep that gave up).  When either
 // is non-zero the gradients of this step are not trustworthy: nothing is updated, the parameters stay what they were.
+// fin (optional, arcvae_adam_update_finalize): the single-process step's loss finalize -- CE row sums -> stats[2Z+3], recon and
+// total scalars, the guard's NaN poison (latent.hip: recon_finalize_kernel) -- done by block 0 of THIS launch: one kernel less in
+// the exposed tail of the step (round 4).
+struct AdamFinalize {
+    const float* rowloss; float* stats; float* scalars; int B, Z, T;
+};
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n4, long n,
                                                    float lr, float b1, float b2, float omb1, float omb2, float eps,
-                                                   const unsigned* guard_a, const unsigned* guard_b) {
+                                                   const unsigned* guard_a, const unsigned* guard_b, AdamFinalize fin) {
 #pragma clang fp contract(off)
-    if ((guard_a && __hip_atomic_load(guard_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
-        (guard_b && __hip_atomic_load(guard_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
-        return;
+    const bool tripped = (guard_a && __hip_atomic_load(guard_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
+                         (guard_b && __hip_atomic_load(guard_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+    if (fin.rowloss && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < fin.B; i += 256) s += fin.rowloss[i];
+        __shared__ float red[4];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* sc = fin.scalars;
+            const float ce = (red[0] + red[1]) + (red[2] + red[3]);
+            fin.stats[2 * fin.Z + 3] = ce;
+            const float recon = ce / (fin.stats[2 * fin.Z + 2] * (float)fin.T);
+            sc[1] = recon;
+            sc[0] = recon + sc[3] + sc[4] + sc[6] + sc[8];
+            sc[15] = 0.0f;
+            if (tripped) {
+                for (int i = 0; i < 9; ++i) sc[i] = __builtin_nanf("");
+                sc[15] = 1.0f;
+            }
+        }
+    }
+    if (tripped) return;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -555,8 +582,31 @@ extern "C" int arcvae_adam_update(float* params, const float* grads, float* m, f
     const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
     const long work = n4 > 0 ? n4 : n;
     const int blocks = (int)min((long)2048, (work + 255) / 256);
+    AdamFinalize fin;
+    fin.rowloss = nullptr; fin.stats = nullptr; fin.scalars = nullptr; fin.B = fin.Z = fin.T = 0;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, m, v, n4, n, (float)lr,
-                       (float)beta1, (float)beta2, omb1, omb2, (float)eps, guard_a, guard_b);
+                       (float)beta1, (float)beta2, omb1, omb2, (float)eps, guard_a, guard_b, fin);
+    return arcvae_launch_status();
+}
+
+// arcvae_recon_finalize + arcvae_adam_update in ONE launch (the tail of the single-process step: trainer.py:320-366 reads the
+// loss after the update was applied): block 0 first sums the CE rows into stats[2Z+3] and writes the recon / total scalars (NaN +
+// scalars[15] = 1 when a guard word is set), every block then applies the un-bias-corrected Adam update (skipped on a guard).
+extern "C" int arcvae_adam_update_finalize(float* params, const float* grads, float* m, float* v, long n, double lr,
+                                           double beta1, double beta2, double eps, const unsigned* guard_a,
+                                           const unsigned* guard_b, const float* rowloss, int B, float* stats, float* scalars,
+                                           int Z, int T, hipStream_t stream) {
+    if (!params || !grads || !m || !v || n <= 0 || !rowloss || !stats || !scalars || B <= 0 || Z <= 0 || T <= 0) return ARCVAE_ERR_ARG;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
+                         reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v);
+    const long n4 = (al & 15) ? 0 : n / 4;
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    const long work = n4 > 0 ? n4 : n;
+    const int blocks = (int)min((long)2048, (work + 255) / 256);
+    AdamFinalize fin;
+    fin.rowloss = rowloss; fin.stats = stats; fin.scalars = scalars; fin.B = B; fin.Z = Z; fin.T = T;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, m, v, n4, n, (float)lr,
+                       (float)beta1, (float)beta2, omb1, omb2, (float)eps, guard_a, guard_b, fin);
     return arcvae_launch_status();
 }
 
