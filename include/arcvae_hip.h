@@ -259,6 +259,21 @@ int arcvae_enc_heads_forward(const float* hT, const float* cond, const float* Wc
                              const float* Wlv, const float* blv, const float* eps, float* comb, float* lh,
                              float* mu_raw, float* lv_raw, float* mu, float* logvar, float* z, float* stats,
                              int B, int H, int Z, int C, float free_bits, int comb_ready, arcvae_stream_t stream);
+/* The whole SEAM between the two sweeps as ONE per-XCD launch (OPT-IN, ARCVAE_SEAM_FUSED=1: parity-green, measured slower than the
+ * five launches it replaces -- csrc/latent.hip; latency regime: B <= 64, hidden_dim a multiple of 64 up to 256, latent_dim a
+ * multiple of 32 up to 128; arcvae_enc_seam_ok says whether the engine is to use it): arcvae_enc_heads_forward (comb_ready form) + arcvae_latent_loss (with
+ * gradients) + arcvae_enc_heads_backward (phase 1) -- models/encoder.py:106-153, complete_vae_loss.py:45-99 and the heads' backward
+ * up to dcomb -- with the batch rows partitioned over the 8 XCDs as in the persistent sweeps, every weight slice requested into LDS
+ * when the block starts, activations exchanged through the XCD's L2, and the batch statistics (Q11) as atomics plus one device-wide
+ * arrival counter.  phases: 1 = forward part (leaves this process's partial `stats`), 2 = backward part from GLOBAL stats (a
+ * data-parallel step all-reduces `stats` between the two launches), 3 = both in one launch.  comb [B,2H] complete; stats [2Z+4]
+ * zeroed ahead of the forward part; sync_ws: the sweeps' scratch -- words [4864, 5696) are the seam's (flags bit 0: zeroed ahead of
+ * the step by arcvae_enc_prologue with n_sync >= 5696); sync_ws[500] != 0 afterwards = a block gave up waiting (sticky). */
+int arcvae_enc_seam_ok(int B, int H, int Z);
+int arcvae_enc_seam(const float* comb, const float* Wmu, const float* bmu, const float* Wlh, const float* blh, const float* Wlv,
+                    const float* blv, const float* eps, const float* hyper, float* lh, float* mu_raw, float* lv_raw, float* mu,
+                    float* logvar, float* z, float* stats, float* scalars, float* dmu_raw, float* dlv_raw, float* dlh, float* dcomb,
+                    unsigned* sync_ws, int B, int H, int Z, int T, float free_bits, int phases, int flags, arcvae_stream_t stream);
 int arcvae_stats_set_recon(const float* rowloss, int B, float* stats, int Z, arcvae_stream_t stream);
 /* complete_vae_loss.py:45-99 (+ losses/kl.py, losses/info.py reductions) from GLOBAL stats.
  * hyper [8] device: beta, lambda_collapse, lambda_mi, target_mi, free_bits; scalars [16] device out:

@@ -68,6 +68,8 @@ SIGNATURES = {
     "arcvae_enc_lstm_backward": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _lp, _vp, _vp, _vp, _vp],
     "arcvae_enc_lstm_wgrad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _lp, _vp],
     "arcvae_enc_heads_forward": [_vp] * 19 + [_i, _i, _i, _i, _f, _i, _vp],
+    "arcvae_enc_seam_ok": [_i, _i, _i],
+    "arcvae_enc_seam": [_vp] * 22 + [_i, _i, _i, _i, _f, _i, _i, _vp],
     "arcvae_stats_set_recon": [_vp, _i, _vp, _i, _vp],
     "arcvae_latent_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "arcvae_loss_finalize": [_vp, _vp, _i, _i, _vp, _vp, _vp],

@@ -101,8 +101,10 @@ class Workspace:
         #                                          BPTT sweeps' at [512, 848), [500] = the sticky error word of both; the
         #                                          two-group forms' (129..256 rows per GPU) at [1024, 4352)
         # words a step's prologue re-arms (arcvae_enc_lstm_persist_groups: two groups of 16 rows per XCD, two blocks per CU)
-        self.psync_words = 4864   # (one-group sweeps: [0, 848); two-group forms: [1024, 4352); the reduce-scatter sweep's
-        #                           "gathered" words of its single-buffered exchange: [4352, 4864))
+        self.psync_words = 5696   # (one-group sweeps: [0, 848); two-group forms: [1024, 4352); the reduce-scatter sweep's
+        #                           "gathered" words of its single-buffered exchange: [4352, 4864); the fused seam's: [4864, 5696))
+        self.seam_bwd_done = False               # this step's fused seam launch has already written the loss scalars, d(mu_raw),
+        #                                          d(lv_raw), dlh and dcomb (EncoderBackwardPlan.heads skips its dcomb chain once)
         self.bptt_rearmed = False                # the prologue of this step's forward has zeroed the BPTT sweep's words too
         # optional diagnostic stamps of the sweep launches / ticks (StepEngine.enable_trace), passed per call
         self.trace_fwd: Optional[torch.Tensor] = None
@@ -202,10 +204,32 @@ def persistent_forward_ok(ws: Workspace, d: ModelDims) -> bool:
     return _lib.load().arcvae_enc_lstm_persistent_ok(ws.B, ws.T, d.H, d.L) == 1
 
 
+def seam_fused_ok(ws: Workspace, d: ModelDims) -> bool:
+    """The chain between the two sweeps of this shape runs as the fused per-XCD seam kernel (csrc/latent.hip: enc_seam_kernel):
+    behind a persistent forward sweep (comb and the zeroed stats are ready, the sync words re-armed by the prologue)."""
+    return persistent_forward_ok(ws, d) and _lib.load().arcvae_enc_seam_ok(ws.B, d.H, d.Z) == 1
+
+
+def encoder_seam(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: float, phases: int) -> None:
+    """arcvae_enc_seam: phases 1 = heads forward + statistics, 2 = loss scalars + latent gradients + dlh + dcomb from GLOBAL
+    stats, 3 = both in one launch (single process)."""
+    train = (phases & 2) != 0
+    call("arcvae_enc_seam", ptr(ws.comb), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
+         ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar_hidden.bias")), ptr(enc.p("fc_logvar.weight")),
+         ptr(enc.p("fc_logvar.bias")), ptr(ws.eps), ptr(ws.hyper), ptr(ws.lh), ptr(ws.mu_raw), ptr(ws.lv_raw), ptr(ws.mu),
+         ptr(ws.logvar), ptr(ws.z), ptr(ws.stats), ptr(ws.scalars), ptr(ws.dmu_raw) if train else C.c_void_p(0),
+         ptr(ws.dlv_raw) if train else C.c_void_p(0), ptr(ws.dlh) if train else C.c_void_p(0),
+         ptr(ws.dcomb) if train else C.c_void_p(0), ptr(ws.psync), ws.B, d.H, d.Z, ws.T, float(free_bits), phases, 1, stream_ptr())
+    if train:
+        ws.seam_bwd_done = True
+
+
 def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: float,
-                    start_signal: Optional[C.c_void_p] = None, zero_grad: bool = False) -> None:
+                    start_signal: Optional[C.c_void_p] = None, zero_grad: bool = False, seam: int = 1) -> None:
     """models/encoder.py:76-153 + per-rank latent statistics.  start_signal (persistent sweep only): device word
-    bumped when the sweep starts.  zero_grad: also clear the encoder's gradient buffer (start of a training step)."""
+    bumped when the sweep starts.  zero_grad: also clear the encoder's gradient buffer (start of a training step).
+    seam = 3 (single-process training step): where the fused seam kernel applies, it also runs the loss + dcomb chain
+    (sets ws.seam_bwd_done: the caller skips arcvae_latent_loss and the heads' phase 1)."""
     B, T = ws.B, ws.T
     G = 4 * d.H
     s = stream_ptr()
@@ -249,6 +273,9 @@ def encoder_forward(enc: ParamStore, ws: Workspace, d: ModelDims, free_bits: flo
         call("arcvae_enc_lstm_forward", ptr(ws.x_tb), ptr(ws.table0), wx, wh, bs, ptr(ws.hseq), ptr(ws.hseq_t),
              ptr(ws.cseq), ptr(ws.gseq), ptr(ws.wt), wT, B, T, d.V, d.H, d.L, _lstm_flags(ws), _caps(ws),
              _oct(ws, "h_oct"), ptr(ws.trace_fwd), s)
+    if comb_ready and seam_fused_ok(ws, d):
+        encoder_seam(enc, ws, d, free_bits, 3 if (seam == 3 and hasattr(ws, "dcomb")) else 1)
+        return
     hT = ws.hseq[d.L - 1, T - 1]  # [B,H] contiguous slab: last padded position (Q3)
     call("arcvae_enc_heads_forward", ptr(hT), ptr(ws.cond), ptr(enc.p("condition_fc.weight")),
          ptr(enc.p("condition_fc.bias")), ptr(enc.p("fc_mu.weight")), ptr(enc.p("fc_mu.bias")),
@@ -528,6 +555,11 @@ class EncoderBackwardPlan:
 
     def heads(self, phase: int) -> None:
         enc, ws, d = self.enc, self.ws, self.d
+        if phase in (0, 1) and getattr(ws, "seam_bwd_done", False):
+            ws.seam_bwd_done = False           # the fused seam launch of this step has written dlh / dcomb already
+            if phase == 1:
+                return
+            phase = 2
         call("arcvae_enc_heads_backward", ptr(ws.cond), ptr(enc.p("fc_mu.weight")),
              ptr(enc.p("fc_logvar_hidden.weight")), ptr(enc.p("fc_logvar.weight")), ptr(ws.comb), ptr(ws.lh),
              ptr(ws.dmu_raw), ptr(ws.dlv_raw), ptr(ws.dlh), ptr(ws.dcomb), ptr(enc.g("condition_fc.weight")),
@@ -1114,8 +1146,8 @@ class StepEngine:
             run("dec_bwd", dec_bwd, self.side)
             self.ev_dec_bwd.record(self.side)
 
-    def _enc_fwd(self, ws: Workspace, backward: bool, start_signal=None) -> None:
-        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]), start_signal, zero_grad=backward)
+    def _enc_fwd(self, ws: Workspace, backward: bool, start_signal=None, seam: int = 1) -> None:
+        encoder_forward(self.enc, ws, self.d, float(self.hyper_host["free_bits"]), start_signal, zero_grad=backward, seam=seam)
 
     def enqueue_encoder_forward(self, ws: Workspace, run=_inline, backward: bool = True, start_signal=None) -> None:
         """Encoder forward on the current stream; leaves this process's partial latent `stats` (the CE slot
@@ -1131,8 +1163,11 @@ class StepEngine:
 
         def prologue():
             if fuse_forward:
-                self._enc_fwd(ws, True, start_signal)
-            latent_loss(ws, self.d, fb, True)
+                self._enc_fwd(ws, True, start_signal, seam=3)      # (fused seam: loss + dcomb chain in the same launch)
+            elif seam_fused_ok(ws, self.d):
+                encoder_seam(self.enc, ws, self.d, fb, 2)          # data-parallel step: `stats` is global by now
+            if not ws.seam_bwd_done:
+                latent_loss(ws, self.d, fb, True)
 
         # the tail chunk's token-table half goes to the SIDE stream: the decoder finished long ago and, unlike a
         # fourth stream, `side` owns a hardware queue of its own (HIP maps streams onto 4 queues), so the two

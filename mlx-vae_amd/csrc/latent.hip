@@ -15,6 +15,7 @@
 //               [7] mutual_info [8] mi_penalty [9] d(total)/d(mi_raw) [10] global rows
 #include "ops.h"
 #include "skinny.h"
+#include "xcd.h"
 
 namespace {
 
@@ -539,6 +540,434 @@ extern "C" int arcvae_enc_heads_backward(const float* cond, const float* Wmu, co
         }
         if ((rc = arcvae_colsum_accum(dcomb + H, B, H, H2, dbc, 1.0f, stream))) return rc;
     }
+    return arcvae_launch_status();
+}
+
+// =============================================================================================
+// The SEAM between the two sweeps as ONE per-XCD kernel (round 4).  At the default shape the chain between
+// the forward sweep's last tick and the BPTT sweep's first was five launches -- [mu_raw | lh], lv_raw + bounds + reparameterise +
+// statistics, latent loss + gradients, [dmu_raw . Wmu | dlh], dcomb -- of 5-12 us each for ~0.1 GFLOP: 36 us of launch seams, cold
+// operand fetches and pipeline fill on the step's critical chain (profiles/r04_timeline_base.txt).  Here the batch rows are
+// partitioned over the 8 XCDs exactly as in the sweeps (XCD x owns rows [x RX, x RX + RX), RX = ceil(B / 8) <= 8), an XCD's 32 CUs
+// split the OUTPUT COLUMNS of every product (Z/32 latent columns, 2H/32 hidden columns each), every weight slice a CU will need in
+// any phase is requested into LDS when the block starts (96 KB at the default shape: the loads of all five products fly at once),
+// activations are exchanged through the XCD's L2 behind the sweeps' flag-line barrier, and the only cross-XCD step -- the batch
+// statistics of the MI term (Q11) -- is f32 atomics into `stats` plus one device-wide arrival counter.
+//   phases bit 0: forward part (models/encoder.py:106-153: heads, tanh bounds, z, this process's partial `stats`)
+//   phases bit 1: backward part from GLOBAL stats (complete_vae_loss.py:45-99 scalars, d/d(mu_raw, lv_raw), dlh, dcomb)
+//   3: both in one launch (single process); data-parallel steps launch 1, all-reduce `stats`, launch 2.
+// Same arithmetic as the launches it replaces (k-ordered f32 FMA chains; libm tanhf / expf / logf); statistics by atomics as before.
+namespace {
+struct SeamArgs {
+    const float *comb, *Wmu, *bmu, *Wlh, *blh, *Wlv, *blv, *eps, *hyper;
+    float *lh, *mu_raw, *lv_raw, *mu, *logvar, *z, *stats, *scalars, *dmu_raw, *dlv_raw, *dlh, *dcomb;
+    unsigned* sync;      // sync_ws (xcd.h: PSEAM words, PS_ERR)
+    int B, H2, Z, T, RX, phases, launch;
+    int dbg;             // timing experiments only (ARCVAE_SEAM_DEBUG = n: every block returns at stop point n; results are WRONG)
+    float fb_min;
+};
+constexpr int SEAM_R = 8;     // rows per XCD at most
+
+// per-XCD barrier (the sweeps' protocol: every storing thread drains its stores to the L2, then ONE plain flag store per CU on
+// the XCD's flag line, polled with agent-scope loads by one wave); false: a bounded spin expired (error word raised)
+__device__ __forceinline__ bool seam_xcd_barrier(unsigned* my_flag, const unsigned* xflags, unsigned epoch, unsigned* err,
+                                                 unsigned* s_ok) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ps_stores_in_l2();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(my_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wave == 1) {
+        unsigned spins = 0;
+        while (true) {
+            const unsigned v = (lane < 32) ? __hip_atomic_load(xflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+            if (__all((int)(v - epoch) >= 0)) break;
+            if (++spins > 4000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (lane == 0) { atomicAdd(err, 1u); *s_ok = 0; }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+__global__ __launch_bounds__(256) void enc_seam_kernel(SeamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ unsigned s_role, s_xcc, s_ok;
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, H2 = a.H2, Z = a.Z, Zc = Z >> 5, Hc = H2 >> 5, LDW = H2 + 4, LDZ = Z + 4;
+    unsigned* err = a.sync + PS_ERR;
+    if (tid == 0) {
+        s_xcc = ps_xcc_id();
+        s_role = atomicAdd(a.sync + PSEAM_CNT + 8 * a.launch + (s_xcc & 7), 1u);
+        s_ok = 1;
+    }
+    __syncthreads();
+    const unsigned xcc = __builtin_amdgcn_readfirstlane(s_xcc), role = __builtin_amdgcn_readfirstlane(s_role);
+    if (xcc >= 8 || role >= 32) {                     // no slot on this XCD: the others time out and drain
+        if (tid == 0) atomicAdd(err, 1u);
+        return;
+    }
+    const int row0 = xcc * a.RX, RXl = max(0, min(a.RX, B - row0));
+    unsigned* my_flag = a.sync + PSEAM + xcc * 32 + role;
+    const unsigned* xflags = a.sync + PSEAM + xcc * 32;
+    const bool fwd = (a.phases & 1) != 0, bwd = (a.phases & 2) != 0;
+    // LDS: weight slices of every phase, the XCD's activation rows, the exchanged gradient rows
+    float* wA = sm;                                   // [(Zc + Hc)][LDW]: rows of Wmu (my Zc), then of Wlh (my Hc)
+    float* wB = wA + (Zc + Hc) * LDW;                 // [Zc][LDW]: rows of Wlv
+    float* wD = wB + Zc * LDW;                        // [Z][Hc]: Wlv[:, my columns]
+    float* wE1 = wD + Z * Hc;                         // [Z][Hc]: Wmu[:, my columns]
+    float* wE2 = wE1 + Z * Hc;                        // [H2][Hc]: Wlh[:, my columns]
+    float* act = wE2 + H2 * Hc;                       // [8][LDW]: comb rows, then lh rows, then dlh rows of my XCD
+    float* g1 = act + SEAM_R * LDW;                   // [8][LDZ] dmu_raw rows
+    float* g2 = g1 + SEAM_R * LDZ;                    // [8][LDZ] dlv_raw rows
+    float* mr = g2 + SEAM_R * LDZ;                    // [8][8] my mu_raw values
+    float* lhown = mr + SEAM_R * 8;                   // [8][Hc] my lh values
+    // ---- every weight slice, requested now (16-byte loads; the phases find them in LDS)
+    const int q4 = H2 >> 2;                           // float4 per weight row
+    if (fwd) {
+        for (int i = tid; i < (Zc + Hc) * q4; i += 256) {
+            const int r = i / q4, k4 = i - r * q4;
+            const float* src = r < Zc ? a.Wmu + (long)(role * Zc + r) * H2 : a.Wlh + (long)(role * Hc + r - Zc) * H2;
+            *reinterpret_cast<f32x4*>(wA + r * LDW + 4 * k4) = *reinterpret_cast<const f32x4*>(src + 4 * k4);
+        }
+        for (int i = tid; i < Zc * q4; i += 256) {
+            const int r = i / q4, k4 = i - r * q4;
+            *reinterpret_cast<f32x4*>(wB + r * LDW + 4 * k4) = *reinterpret_cast<const f32x4*>(a.Wlv + (long)(role * Zc + r) * H2 + 4 * k4);
+        }
+        for (int i = tid; i < RXl * q4; i += 256) {   // comb rows of my XCD (written by the sweep's last tick + the prologue)
+            const int r = i / q4, k4 = i - r * q4;
+            *reinterpret_cast<f32x4*>(act + r * LDW + 4 * k4) = *reinterpret_cast<const f32x4*>(a.comb + (long)(row0 + r) * H2 + 4 * k4);
+        }
+    }
+    if (bwd) {
+        const int c4 = Hc >> 2;
+        for (int i = tid; i < Z * c4; i += 256) {
+            const int j = i / c4, c = i - j * c4;
+            *reinterpret_cast<f32x4*>(wD + j * Hc + 4 * c) = *reinterpret_cast<const f32x4*>(a.Wlv + (long)j * H2 + role * Hc + 4 * c);
+            *reinterpret_cast<f32x4*>(wE1 + j * Hc + 4 * c) = *reinterpret_cast<const f32x4*>(a.Wmu + (long)j * H2 + role * Hc + 4 * c);
+        }
+        for (int i = tid; i < H2 * c4; i += 256) {
+            const int k = i / c4, c = i - k * c4;
+            *reinterpret_cast<f32x4*>(wE2 + k * Hc + 4 * c) = *reinterpret_cast<const f32x4*>(a.Wlh + (long)k * H2 + role * Hc + 4 * c);
+        }
+    }
+    __syncthreads();
+    if (a.dbg == 1) return;
+    // thread roles: phase B / C: (row i, my latent column jq), K split over 8 lanes;  phases D / E: (row i, my hidden column q), K over 2
+    const int oB = tid >> 3, sB = tid & 7, iB = oB & 7, jq = oB >> 3;
+    const bool ownB = sB == 0 && jq < Zc && iB < RXl;
+    const int jcol = role * Zc + min(jq, Zc - 1);
+    const int oD = tid >> 1, sD = tid & 1, iD = oD & 7, qD = oD >> 3;
+    const bool actD = qD < Hc && iD < RXl;
+    float m_v = 0.f, lv_v = 0.f;                      // my (row, latent column): mu, logvar
+    if (fwd) {
+        // ---- phase A: [mu_raw | lh = tanh(.)] of my XCD's rows, my columns
+        if (tid < 8 * (Zc + Hc)) {
+            const int i = tid & 7, c = tid >> 3;
+            if (i < RXl) {
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(wA + c * LDW);
+                const f32x4* x4 = reinterpret_cast<const f32x4*>(act + i * LDW);
+                // (four independent chains, eight 16-byte LDS reads in flight: one dependent chain over K ran at an LDS round trip
+                // per step -- 5.3 us for this phase; ARCVAE_SEAM_DEBUG stop points, tools/r4_seam_alone.py)
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+                for (int k = 0; k < q4; k += 4) {
+                    const f32x4 w0 = w4[k], x0 = x4[k], w1 = w4[k + 1], x1 = x4[k + 1], w2 = w4[k + 2], x2 = x4[k + 2], w3 = w4[k + 3], x3 = x4[k + 3];
+                    a0 = fmaf(x0[0], w0[0], a0); a0 = fmaf(x0[1], w0[1], a0); a0 = fmaf(x0[2], w0[2], a0); a0 = fmaf(x0[3], w0[3], a0);
+                    a1 = fmaf(x1[0], w1[0], a1); a1 = fmaf(x1[1], w1[1], a1); a1 = fmaf(x1[2], w1[2], a1); a1 = fmaf(x1[3], w1[3], a1);
+                    a2 = fmaf(x2[0], w2[0], a2); a2 = fmaf(x2[1], w2[1], a2); a2 = fmaf(x2[2], w2[2], a2); a2 = fmaf(x2[3], w2[3], a2);
+                    a3 = fmaf(x3[0], w3[0], a3); a3 = fmaf(x3[1], w3[1], a3); a3 = fmaf(x3[2], w3[2], a3); a3 = fmaf(x3[3], w3[3], a3);
+                }
+                const float acc = (a0 + a1) + (a2 + a3);
+                if (c < Zc) {
+                    const int col = role * Zc + c;
+                    const float v = acc + a.bmu[col];
+                    a.mu_raw[(long)(row0 + i) * Z + col] = v;
+                    mr[i * 8 + c] = v;
+                } else {
+                    const int col = role * Hc + c - Zc;
+                    const float v = tanhf(acc + a.blh[col]);
+                    a.lh[(long)(row0 + i) * H2 + col] = v;
+                    lhown[i * Hc + c - Zc] = v;
+                }
+            }
+        }
+        if (a.dbg == 2) return;
+        if (!seam_xcd_barrier(my_flag, xflags, 1u, err, &s_ok)) return;
+        if (a.dbg == 3) return;
+        // ---- phase B: lv_raw from the XCD's lh rows, then bounds, z and my share of the batch statistics
+        if (RXl > 0) {
+            const __amdgpu_buffer_rsrc_t rs = ps_rsrc(a.lh + (long)row0 * H2, (long)RXl * H2 * 4);
+            for (int i = tid; i < RXl * q4; i += 256) {
+                const int r = i / q4, k4 = i - r * q4;
+                *reinterpret_cast<f32x4*>(act + r * LDW + 4 * k4) = ps_load_sc1_x4(rs, (unsigned)((r * H2 + 4 * k4) * 4));
+            }
+        }
+        __syncthreads();
+        float part = 0.f;
+        if (jq < Zc && iB < RXl) {
+            const int kn = H2 >> 3, k0 = sB * kn;      // my eighth of K
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(wB + jq * LDW + k0);
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(act + iB * LDW + k0);
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < (kn >> 2); k += 2) {
+                const f32x4 w0 = w4[k], x0 = x4[k], w1 = w4[k + 1], x1 = x4[k + 1];
+                p0 = fmaf(x0[0], w0[0], p0); p0 = fmaf(x0[1], w0[1], p0); p0 = fmaf(x0[2], w0[2], p0); p0 = fmaf(x0[3], w0[3], p0);
+                p1 = fmaf(x1[0], w1[0], p1); p1 = fmaf(x1[1], w1[1], p1); p1 = fmaf(x1[2], w1[2], p1); p1 = fmaf(x1[3], w1[3], p1);
+            }
+            part = p0 + p1;
+        }
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+        float mc_v = 0.f, var_v = 0.f, k_v = 0.f, kf_v = 0.f;
+        if (ownB) {
+            const long idx = (long)(row0 + iB) * Z + jcol;
+            const float lvr = part + a.blv[jcol];
+            a.lv_raw[idx] = lvr;
+            const float m = tanhf(mr[iB * 8 + jq] / 2.0f) * 2.0f;
+            const float lv = tanhf(lvr / 2.0f) * 1.0f - 1.0f;
+            a.mu[idx] = m; a.logvar[idx] = lv;
+            a.z[idx] = m + a.eps[idx] * expf(0.5f * lv);
+            m_v = m; lv_v = lv;
+            const float mc = clipf(m, -3.0f, 3.0f), lc = clipf(lv, -6.0f, 3.0f);
+            var_v = expf(lc); mc_v = mc;
+            k_v = -0.5f * (1.0f + lc - mc * mc - var_v);
+            kf_v = fmaxf(k_v, 0.0f);
+            if (a.fb_min > 0.0f) kf_v = fmaxf(kf_v, a.fb_min);
+        }
+        // wave jq holds the 8 rows of latent column jq (lanes with sB == 0): column sums and KL sums by wave reduction
+        mc_v = wave_sum(mc_v); var_v = wave_sum(var_v); k_v = wave_sum(k_v); kf_v = wave_sum(kf_v);
+        // column sums: a column has ONE owner per XCD -> 8 adds per address.  The two KL sums and the row count would take an add from
+        // every wave of every CU (1024 per address, serialised at the memory side: this phase measured 28 us): a CU's partials go
+        // to its own slot, the XCD's CU 0 adds the 32 slots up behind one more flag barrier and issues ONE add per XCD.
+        if (lane == 0 && wave < Zc && RXl > 0) {
+            atomicAdd(a.stats + jcol, mc_v);
+            atomicAdd(a.stats + Z + jcol, var_v);
+        }
+        if (lane == 0) { s_red[wave] = wave < Zc ? k_v : 0.f; s_red[4 + wave] = wave < Zc ? kf_v : 0.f; }
+        __syncthreads();
+        float* xpart = reinterpret_cast<float*>(a.sync + PSEAM_PART) + xcc * 64;
+        if (tid == 0) {
+            xpart[2 * role] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+            xpart[2 * role + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+        }
+        if (!seam_xcd_barrier(my_flag, xflags, 2u, err, &s_ok)) return;
+        if (role == 0 && wave == 0 && RXl > 0) {
+            const __amdgpu_buffer_rsrc_t rp = ps_rsrc(xpart, 64 * 4);
+            float v = ps_load_sc1(rp, (unsigned)(lane * 4));          // lane 2r: CU r's k sum, lane 2r + 1: its free-bits sum
+            v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 2) atomicAdd(a.stats + 2 * Z + lane, v);
+            if (lane == 2) atomicAdd(a.stats + 2 * Z + 2, (float)RXl);
+        }
+        if (!bwd || a.dbg == 4) return;
+        // ---- every block's statistics are in: device-wide arrival counter (the one cross-XCD step of the seam)
+        ps_stores_in_l2();
+        __syncthreads();
+        if (wave == 1) {
+            unsigned* gcnt = a.sync + PSEAM_GCNT;
+            if (lane == 0) __hip_atomic_fetch_add(gcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 256u) {
+                if (++spins > 4000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) { atomicAdd(err, 1u); s_ok = 0; }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (!s_ok || a.dbg == 5) return;
+    } else {
+        // backward part on its own (data-parallel step: `stats` was all-reduced in between): my values back from memory
+        if (ownB) {
+            const long idx = (long)(row0 + iB) * Z + jcol;
+            m_v = a.mu[idx]; lv_v = a.logvar[idx];
+        }
+        if (sD == 0 && actD) lhown[iD * Hc + qD] = a.lh[(long)(row0 + iD) * H2 + role * Hc + qD];
+    }
+    // ---- phase C: loss scalars from the GLOBAL statistics (agent-scope loads: other XCDs' atomics), d/d(mu_raw, lv_raw) of mine
+    float cmi, Bg;
+    {
+        const float bg = __hip_atomic_load(a.stats + 2 * Z + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float t = 0.f;
+        for (int j = tid; j < Z; j += 256) {
+            const float mm = __hip_atomic_load(a.stats + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / bg;
+            const float mv = __hip_atomic_load(a.stats + Z + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / bg;
+            t += 1.0f + logf(mv) - mm * mm - mv;
+        }
+        t = wave_sum(t);
+        if (lane == 0) s_red[wave] = t;
+        __syncthreads();
+        const float tot = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        const float agg = -0.5f * tot;
+        const float beta = a.hyper[0], lc = a.hyper[1], lmi = a.hyper[2], target = a.hyper[3];
+        const float mean_kl = __hip_atomic_load(a.stats + 2 * Z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / bg;
+        const float mi_raw = mean_kl - agg;
+        const float mi = mi_raw > 0.0f ? mi_raw : 0.0f;
+        const float d = target - mi;
+        const bool gate = !(0.0f > d);
+        const float dpos = gate ? d : 0.0f;
+        cmi = (gate && mi_raw > 0.0f) ? -(lc + lmi) : 0.0f;
+        Bg = bg;
+        if (xcc == 0 && role == 0 && tid == 0) {
+            LatentScalars r;
+            r.mi = mi; r.collapse = lc * dpos; r.mi_pen = lmi * dpos;
+            r.kl = __hip_atomic_load(a.stats + 2 * Z + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / bg;
+            r.recon = __hip_atomic_load(a.stats + 2 * Z + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (bg * (float)a.T);
+            r.wkl = beta * r.kl;
+            r.total = r.recon + r.wkl + r.collapse + 0.0f + r.mi_pen;
+            r.cmi = cmi; r.Bg = bg;
+            latent_scalars_write(r, a.scalars);
+        }
+    }
+    if (ownB) {
+        const long idx = (long)(row0 + iB) * Z + jcol;
+        const float beta = a.hyper[0];
+        const float m = m_v, lv = lv_v;
+        const float pm = (m > -3.0f && m < 3.0f) ? 1.0f : 0.0f;
+        const float pl = (lv > -6.0f && lv < 3.0f) ? 1.0f : 0.0f;
+        const float mc = clipf(m, -3.0f, 3.0f), lc = clipf(lv, -6.0f, 3.0f);
+        const float var = expf(lc);
+        const float k = -0.5f * (1.0f + lc - mc * mc - var);
+        const bool live = (k > 0.0f) && !(a.fb_min > 0.0f && !(k > a.fb_min));
+        float gm = 0.f, gl = 0.f;
+        if (live) {
+            gm += beta * mc / Bg;
+            gl += beta * 0.5f * (var - 1.0f) / Bg;
+        }
+        if (cmi != 0.0f) {
+            const float mm = __hip_atomic_load(a.stats + jcol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / Bg;
+            const float mv = __hip_atomic_load(a.stats + Z + jcol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / Bg;
+            gm += cmi * (mc - mm) / Bg;
+            gl += cmi * 0.5f * (var / mv - 1.0f) / Bg;
+        }
+        gm *= pm;
+        gl *= pl;
+        const float hm = 0.5f * m, hl = lv + 1.0f;
+        a.dmu_raw[idx] = gm * (1.0f - hm * hm);
+        a.dlv_raw[idx] = gl * 0.5f * (1.0f - hl * hl);
+    }
+    if (a.dbg == 6) return;
+    if (!seam_xcd_barrier(my_flag, xflags, 3u, err, &s_ok)) return;
+    if (a.dbg == 7) return;
+    // ---- phase D: dlh = (dlv_raw . Wlv) (1 - lh^2) for my columns; the dmu_raw . Wmu half of dcomb rides along
+    if (RXl > 0) {
+        const __amdgpu_buffer_rsrc_t r1 = ps_rsrc(a.dmu_raw + (long)row0 * Z, (long)RXl * Z * 4);
+        const __amdgpu_buffer_rsrc_t r2 = ps_rsrc(a.dlv_raw + (long)row0 * Z, (long)RXl * Z * 4);
+        const int z4 = Z >> 2;
+        for (int i = tid; i < RXl * z4; i += 256) {
+            const int r = i / z4, k4 = i - r * z4;
+            *reinterpret_cast<f32x4*>(g1 + r * LDZ + 4 * k4) = ps_load_sc1_x4(r1, (unsigned)((r * Z + 4 * k4) * 4));
+            *reinterpret_cast<f32x4*>(g2 + r * LDZ + 4 * k4) = ps_load_sc1_x4(r2, (unsigned)((r * Z + 4 * k4) * 4));
+        }
+    }
+    __syncthreads();
+    float dl = 0.f, dcm = 0.f;
+    if (actD) {
+        const int jn = Z >> 1, j0 = sD * jn;
+        float d0 = 0.f, d1 = 0.f, c0 = 0.f, c1 = 0.f;
+#pragma unroll 2
+        for (int j = j0; j < j0 + jn; j += 4) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g2 + iD * LDZ + j), mv = *reinterpret_cast<const f32x4*>(g1 + iD * LDZ + j);
+            const float u0 = wD[j * Hc + qD], u1 = wD[(j + 1) * Hc + qD], u2 = wD[(j + 2) * Hc + qD], u3 = wD[(j + 3) * Hc + qD];
+            const float t0 = wE1[j * Hc + qD], t1 = wE1[(j + 1) * Hc + qD], t2 = wE1[(j + 2) * Hc + qD], t3 = wE1[(j + 3) * Hc + qD];
+            d0 = fmaf(gv[0], u0, d0); d1 = fmaf(gv[1], u1, d1); d0 = fmaf(gv[2], u2, d0); d1 = fmaf(gv[3], u3, d1);
+            c0 = fmaf(mv[0], t0, c0); c1 = fmaf(mv[1], t1, c1); c0 = fmaf(mv[2], t2, c0); c1 = fmaf(mv[3], t3, c1);
+        }
+        dl = d0 + d1; dcm = c0 + c1;
+    }
+    dl += __shfl_xor(dl, 1, 64);
+    if (sD == 0 && actD) {
+        const float t = lhown[iD * Hc + qD];
+        a.dlh[(long)(row0 + iD) * H2 + role * Hc + qD] = dl * (1.0f - t * t);
+    }
+    if (a.dbg == 8) return;
+    if (!seam_xcd_barrier(my_flag, xflags, 4u, err, &s_ok)) return;
+    if (a.dbg == 9) return;
+    // ---- phase E: dcomb = dmu_raw . Wmu + dlh . Wlh for my columns
+    if (RXl > 0) {
+        const __amdgpu_buffer_rsrc_t rs = ps_rsrc(a.dlh + (long)row0 * H2, (long)RXl * H2 * 4);
+        for (int i = tid; i < RXl * q4; i += 256) {
+            const int r = i / q4, k4 = i - r * q4;
+            *reinterpret_cast<f32x4*>(act + r * LDW + 4 * k4) = ps_load_sc1_x4(rs, (unsigned)((r * H2 + 4 * k4) * 4));
+        }
+    }
+    __syncthreads();
+    if (actD) {
+        const int kn = H2 >> 1, k0 = sD * kn;
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+#pragma unroll 2
+        for (int k = k0; k < k0 + kn; k += 8) {
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(act + iD * LDW + k), xb = *reinterpret_cast<const f32x4*>(act + iD * LDW + k + 4);
+            const float w0 = wE2[k * Hc + qD], w1 = wE2[(k + 1) * Hc + qD], w2 = wE2[(k + 2) * Hc + qD], w3 = wE2[(k + 3) * Hc + qD];
+            const float w4_ = wE2[(k + 4) * Hc + qD], w5 = wE2[(k + 5) * Hc + qD], w6 = wE2[(k + 6) * Hc + qD], w7 = wE2[(k + 7) * Hc + qD];
+            e0 = fmaf(xa[0], w0, e0); e1 = fmaf(xa[1], w1, e1); e2 = fmaf(xa[2], w2, e2); e3 = fmaf(xa[3], w3, e3);
+            e0 = fmaf(xb[0], w4_, e0); e1 = fmaf(xb[1], w5, e1); e2 = fmaf(xb[2], w6, e2); e3 = fmaf(xb[3], w7, e3);
+        }
+        dcm += (e0 + e1) + (e2 + e3);
+    }
+    dcm += __shfl_xor(dcm, 1, 64);
+    if (sD == 0 && actD) a.dcomb[(long)(row0 + iD) * H2 + role * Hc + qD] = dcm;
+}
+
+inline size_t seam_lds_bytes(int H2, int Z) {
+    const int Zc = Z >> 5, Hc = H2 >> 5, LDW = H2 + 4, LDZ = Z + 4;
+    return sizeof(float) * ((size_t)(Zc + Hc) * LDW + (size_t)Zc * LDW + 2 * (size_t)Z * Hc + (size_t)H2 * Hc + (size_t)SEAM_R * LDW +
+                            2 * (size_t)SEAM_R * LDZ + SEAM_R * 8 + (size_t)SEAM_R * Hc);
+}
+}  // namespace
+
+// 1 where arcvae_enc_seam is to be used for the shape: OPT-IN (ARCVAE_SEAM_FUSED=1), at most 8 rows per XCD (B <= 64), hidden_dim a
+// multiple of 64 up to 256, latent_dim a multiple of 32 up to 128, persistent kernels enabled (ARCVAE_PERSIST != 0).
+// Parity-green and measured SLOWER than the five launches it replaces (round 4, default shape, tools/r4_seam_alone.py): 30.9 us
+// alone against 19.2, step 0.987 against 0.963 ms.  The seam is not launch-bound: the five launches spread each product over the
+// whole chip on the matrix cores and a captured launch costs ~4 us; here a CU works its column slice off with FMA chains out of
+// LDS.  Stop points of the kernel alone (us, cumulative): launch + role + every weight slice into LDS 6.4, [mu_raw | lh] 11.0,
+// flag barrier 13.6, lv_raw + bounds + statistics 17.9, device-wide arrival counter 20.4, scalars + latent gradients 22.6,
+// barrier 22.8, dlh 26.1, barrier 26.9, dcomb 30.9 -- ten dependent steps of 2-5 us; before the KL sums were reduced per XCD
+// (one f32 add per XCD instead of one per wave and CU on two addresses) the statistics alone took 28 us.
+extern "C" int arcvae_enc_seam_ok(int B, int H, int Z) {
+    if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0 || arcvae_env_int("ARCVAE_SEAM_FUSED", 0) == 0) return 0;
+    if (B < 1 || B > 8 * SEAM_R || H < 64 || H > 256 || (H % 64) != 0 || Z < 32 || Z > 128 || (Z % 32) != 0) return 0;
+    return seam_lds_bytes(2 * H, Z) <= 150 * 1024 ? 1 : 0;
+}
+
+// models/encoder.py:106-153 + complete_vae_loss.py:45-99 + the heads' backward up to dcomb, as one per-XCD kernel (see above).
+// comb [B,2H] complete (arcvae_enc_prologue + the persistent forward sweep); stats [2Z+4] zeroed ahead of the forward part;
+// sync_ws: the sweeps' scratch (words [4864, 5696) are the seam's; flags bit 0: they were zeroed ahead of the step by
+// arcvae_enc_prologue with n_sync >= 5696).  Outputs: everything arcvae_enc_heads_forward, arcvae_latent_loss(with gradients) and
+// arcvae_enc_heads_backward(phase 1) write.  sync_ws[500] != 0 afterwards = a block gave up waiting.
+extern "C" int arcvae_enc_seam(const float* comb, const float* Wmu, const float* bmu, const float* Wlh, const float* blh,
+                               const float* Wlv, const float* blv, const float* eps, const float* hyper, float* lh, float* mu_raw,
+                               float* lv_raw, float* mu, float* logvar, float* z, float* stats, float* scalars, float* dmu_raw,
+                               float* dlv_raw, float* dlh, float* dcomb, unsigned* sync_ws, int B, int H, int Z, int T,
+                               float free_bits, int phases, int flags, hipStream_t stream) {
+    if (!comb || !Wmu || !bmu || !Wlh || !blh || !Wlv || !blv || !eps || !lh || !mu_raw || !lv_raw || !mu || !logvar || !z ||
+        !stats || !sync_ws)
+        return ARCVAE_ERR_ARG;
+    if (phases < 1 || phases > 3 || T <= 0 || !arcvae_enc_seam_ok(B, H, Z)) return ARCVAE_ERR_ARG;
+    if ((phases & 2) && (!hyper || !scalars || !dmu_raw || !dlv_raw || !dlh || !dcomb)) return ARCVAE_ERR_ARG;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(comb) | reinterpret_cast<uintptr_t>(Wmu) | reinterpret_cast<uintptr_t>(Wlh) |
+                         reinterpret_cast<uintptr_t>(Wlv) | reinterpret_cast<uintptr_t>(lh) | reinterpret_cast<uintptr_t>(dmu_raw) |
+                         reinterpret_cast<uintptr_t>(dlv_raw) | reinterpret_cast<uintptr_t>(dlh);
+    if (al & 15) return ARCVAE_ERR_ARG;
+    if (!(flags & 1)) {
+        const int rc = arcvae_zero(reinterpret_cast<float*>(sync_ws + PSEAM), 1, PSEAM_WORDS - PSEAM, PSEAM_WORDS - PSEAM, stream);
+        if (rc != ARCVAE_OK) return rc;
+    }
+    SeamArgs a;
+    a.comb = comb; a.Wmu = Wmu; a.bmu = bmu; a.Wlh = Wlh; a.blh = blh; a.Wlv = Wlv; a.blv = blv; a.eps = eps; a.hyper = hyper;
+    a.lh = lh; a.mu_raw = mu_raw; a.lv_raw = lv_raw; a.mu = mu; a.logvar = logvar; a.z = z; a.stats = stats; a.scalars = scalars;
+    a.dmu_raw = dmu_raw; a.dlv_raw = dlv_raw; a.dlh = dlh; a.dcomb = dcomb; a.sync = sync_ws;
+    a.B = B; a.H2 = 2 * H; a.Z = Z; a.T = T; a.RX = ceil_div(B, 8); a.phases = phases; a.launch = (phases == 2) ? 1 : 0;
+    a.fb_min = free_bits > 0.0f ? free_bits / (float)Z : 0.0f;
+    a.dbg = arcvae_env_int("ARCVAE_SEAM_DEBUG", 0);
+    const size_t lds = seam_lds_bytes(2 * H, Z);
+    (void)hipFuncSetAttribute((const void*)enc_seam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(enc_seam_kernel, dim3(256), dim3(256), lds, stream, a);
     return arcvae_launch_status();
 }
 

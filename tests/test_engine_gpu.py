@@ -743,3 +743,48 @@ def test_undersized_operand_rings_are_argument_errors_not_overruns(monkeypatch):
     torch.cuda.synchronize()
     eng2.check_gates()
     assert eng2.workspace(B, T, True).hseq_t.shape[1] == T and np.isfinite(float(out["total_loss"]))
+
+
+@pytest.mark.parametrize("H,Z,L,B,T,C", [(256, 128, 2, 64, 12, 1), (256, 128, 2, 37, 9, 2), (128, 32, 2, 5, 7, 1), (128, 64, 1, 21, 6, 1),
+                                         (384, 96, 1, 9, 5, 1), (256, 128, 1, 3, 4, 1)])
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_fused_seam_kernel_against_the_oracle(H, Z, L, B, T, C, fused, monkeypatch):
+    """csrc/latent.hip enc_seam_kernel (round 4): the chain between the two sweeps -- heads forward, tanh bounds, z, batch
+    statistics, loss scalars, latent gradients, dlh, dcomb -- as ONE per-XCD launch (rows partitioned over the XCDs as in the
+    sweeps, weight slices in LDS, exchange through the XCD's L2, one device-wide arrival counter for the statistics).  Shapes it
+    takes: full and ragged row groups (37, 21, 5, 3 rows: XCDs with fewer or no rows), every latent / hidden column count per CU,
+    one and two layers; and ARCVAE_SEAM_FUSED=0 (the default: the kernel measured slower than the five launches it replaces and is
+    opt-in).  1e-4 against the fp64 oracle, both metrics."""
+    import arcvae_hip.engine as E
+    monkeypatch.setenv("ARCVAE_SEAM_FUSED", fused)
+    cfg = O.Config(vocab_size=60, embedding_dim=32, hidden_dim=H, latent_dim=Z, num_conditions=C, num_layers=L)
+    params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
+    vals, grads = _oracle(cfg, params, x, cond, eps, coins)
+    eng, enc, dec = build_engine(cfg, params)
+    for rep in range(3):                               # eager + capture, then two replays
+        out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
+    torch.cuda.synchronize()
+    eng.check_gates()
+    ws = eng.workspace(B, T, True)
+    assert E.seam_fused_ok(ws, eng.d) == (fused == "1" and H <= 256)     # (H 384: persistent forward sweep, seam by launches)
+    for k in ("total_loss", "recon_loss", "kl_loss", "weighted_kl", "collapse_penalty", "mutual_info", "mi_penalty"):
+        assert abs(float(out[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
+    for k in ("mu", "logvar", "z"):
+        assert rel_err(out[k].cpu().numpy(), vals[k]) < TOL, k
+        assert_elem(out[k].cpu().numpy(), vals[k], k, ELEM_ATOL_FWD)
+    bad = {}
+    for name, g in grads.items():
+        mod, pname = name.split(".", 1)
+        got = (enc if mod == "encoder" else dec).g(pname).cpu().numpy()
+        if np.abs(g).max() == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        elif rel_err(got, g) >= TOL:
+            bad[name] = rel_err(got, g)
+        else:
+            assert_elem(got, g, "grad " + name, ELEM_ATOL_GRAD)
+    assert not bad, bad
+    # the forward-only path (validation / logging) takes the kernel's forward part
+    fw = eng.forward_loss(x, cond, eps, coins, **HYPER)
+    torch.cuda.synchronize()
+    for k in ("total_loss", "kl_loss", "mutual_info"):
+        assert abs(float(fw[k]) - float(vals[k])) <= TOL * max(1.0, abs(float(vals[k]))), k
