@@ -560,6 +560,8 @@ def main(argv=None):
                           "dp_form": dp_form(dp2), "gates_ok_all_ranks": True,
                           "bptt_kernel": ("lstm_bwd_persist_rs_kernel" if E.bptt_reduce_scatter_ok(ws2, dims)
                                           else "per-step launches (lstm_bwd_step*/tile kernels)")}
+                if getattr(ws2, "planes", False):   # the leg's contractions run in the three-piece form (tile regime)
+                    strong["step_executed_frac_of_bf16_pipe"] = 6.0 * strong["step_tflops_executed_per_gpu"] / 2500.0
                 if comm2 is not None:
                     strong["comm"] = comm2
                 if rank == 0 and not args.no_roofline:
@@ -701,6 +703,9 @@ def main(argv=None):
                 if prec == "fp32":
                     legs[prec]["frac_of_f32_mfma_peak"] = sq * f_seq2 / 1e12 / PEAK_F32_MFMA_TFLOPS
                     legs[prec]["executed_frac_of_f32_mfma_peak"] = legs[prec]["step_tflops_executed"] / PEAK_F32_MFMA_TFLOPS
+                    # every large contraction of this leg runs in the three-piece form (sweeps, plane GEMMs, dense decoder stack):
+                    # the bf16 products issued per second against the pipe they issue on
+                    legs[prec]["executed_frac_of_bf16_pipe"] = 6.0 * legs[prec]["step_tflops_executed"] / 2500.0
                     if not args.no_roofline:
                         legs[prec]["roofline"] = roofline_probe(eng4, ws4, torch)   # the MFMA-bound regime's dominant kernel, live
                 else:
@@ -803,6 +808,10 @@ def roofline_probe(eng, ws, torch):
               (("lstm_bwd_tile_ks_kernel" if bf16 else "lstm_bwd_tile_ks3_kernel / lstm_bwd_tile_kernel") if tiled else
                ("lstm_bwd_step2_kernel" if B >= 256 else "lstm_bwd_step_kernel")))
     peak = 2500.0 if bf16 else PEAK_F32_MFMA_TFLOPS       # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
+    # three-piece tile kernels (the fp32 parity path of the MFMA-bound regime): every f32 product is SIX products on
+    # v_mfma_f32_16x16x32_bf16 -- what the kernel executes on the bf16 matrix pipe, next to the section-8(d) f32 figure
+    from arcvae_hip import _lib as _L
+    three_piece = bool(tiled and not bf16 and (E._lstm_flags(ws) & _L.LSTM_SPLIT3))
     # traffic: fabric-side bytes per tick / launch from the newest committed rocprofv3 --pmc summary (separate passes,
     # tools/pmc.sh; 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction) -- a profile figure, named by its file, not
     # measured in this run.  tick_model: where a tick's time goes (tools/probe_persist.hip on the same chip).
@@ -855,11 +864,19 @@ def roofline_probe(eng, ws, torch):
                 "dependent-chain seam (1.6 us boundary + cold operand fetch of ~128 KB per CU), see DESIGN.md section 6")
     if bf16:
         note += "  (throughput mode: bf16 operands, so `peak` is the dense bf16 MFMA peak; not the parity path)"
-    return {"bound": "mfma", "limiter": "operand delivery + launch seam" if tiled else "latency", "kernel": kernel, "achieved": ach,
-            "peak": peak,
-            "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
-            "us_per_launch": us, "launches_per_sweep": launches,
-            "flop_per_launch": flops_total / launches, "tick_model": tick_model, "note": note}
+    out = {"bound": "mfma", "limiter": "operand delivery + launch seam" if tiled else "latency", "kernel": kernel, "achieved": ach,
+           "peak": peak,
+           "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
+           "us_per_launch": us, "launches_per_sweep": launches,
+           "flop_per_launch": flops_total / launches, "tick_model": tick_model, "note": note}
+    if three_piece:
+        # ("98 % of the f32 peak" is a ratio against a pipe these kernels do not run on)
+        out["executed_tflops_on_bf16_pipe"] = 6.0 * ach
+        out["executed_frac_of_bf16_pipe"] = 6.0 * ach / 2500.0
+        out["pipe_note"] = ("three-piece form: six v_mfma_f32_16x16x32_bf16 products per f32 product -- `achieved` / `frac` price the "
+                            "f32-equivalent FLOP against the f32 MFMA peak (SURVEY 8(d)); executed_* price the bf16 products "
+                            "actually issued against the dense bf16 peak (2.5 PFLOP/s)")
+    return out
 
 
 if __name__ == "__main__":

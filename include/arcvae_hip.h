@@ -333,6 +333,11 @@ int arcvae_dec_gather_logits(const float* dense, const int32_t* fed, float* out,
 /* models/decoder_sampling.py:85-123 greedy walk: tokens [B,max_len], first_end [B]. */
 int arcvae_dec_sample_chain(const int32_t* nxt, int32_t* tokens, int32_t* first_end, int B, int V,
                             int max_len, int end_token, arcvae_stream_t stream);
+/* EXTENSION (not in the reference, whose sampler is greedy: "for now, use argmax", models/decoder_sampling.py:115-116): true
+ * categorical sampling, tokens[b,t] ~ Categorical(softmax(dense_logits[b, cur, :] / temperature)) walked from the start token,
+ * uniform numbers from a counter-based generator keyed by (seed, row, step): the same seed and batch give the same molecules.  dense_logits [B*V, V] as written by arcvae_dec_forward_dense (mode 0); vocab_size <= 256; first_end as above. */
+int arcvae_dec_sample_chain_categorical(const float* dense_logits, int32_t* tokens, int32_t* first_end, int B, int V, int max_len,
+                                        int end_token, float temperature, unsigned long long seed, arcvae_stream_t stream);
 /* Backward of arcvae_dec_forward_dense: embedding.weight, lstm_layer_l.{Wx,bias}, fc_out.{weight,bias}.
  * ws: dh [2,B*V,H], dG [B*V,4H], dtableD [V,4H], wcpart [V,4H,max(C,1)]. */
 int arcvae_dec_backward_dense(const float* emb, const float* const* Wx, const float* const* bias,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "arcvae_dec_ce_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "arcvae_dec_gather_logits": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "arcvae_dec_sample_chain": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "arcvae_dec_sample_chain_categorical": [_vp, _vp, _vp, _i, _i, _i, _i, _f, C.c_ulonglong, _vp],
     "arcvae_dec_backward_dense": [_vp, _pp, _pp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _pp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "arcvae_reparameterize": [_vp, _vp, _vp, _vp, _l, _vp],

@@ -345,6 +345,64 @@ __global__ __launch_bounds__(64) void dec_sample_chain_kernel(const int32_t* __r
     first_end[b] = fe;
 }
 
+// ---- categorical sampler walk (round 4; the sampling the reference marks TODO, models/decoder_sampling.py:115-116: "for now, use
+// argmax") -- an EXTENSION, not a parity path: tokens[b,t] ~ Categorical(softmax(logits[b, cur, :] / temperature)).  The decoder is
+// stateless (Q1/Q2), so the dense pass has every distribution a row can ever meet; the walk is one wave per batch row: a lane holds
+// up to four vocabulary entries, the row's cumulative distribution is a wave scan, the uniform number of step t comes from a
+// counter-based generator keyed by (seed, row, t) (splitmix64 finaliser: reproducible for a seed whatever the launch shape), and the
+// next token is the first entry whose cumulative mass exceeds u * total.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void dec_sample_categorical_kernel(const float* __restrict__ logits, int32_t* tokens,
+                                                                    int32_t* first_end, int B, int V, int max_len,
+                                                                    int end_token, float inv_temp, unsigned long long seed) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;                                   // wave-uniform
+    int cur = 0, fe = max_len;
+    for (int t = 0; t < max_len; ++t) {
+        const float* row = logits + ((long)b * V + cur) * V;
+        float x[4], mx = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * lane + e;
+            x[e] = j < V ? row[j] * inv_temp : -3.0e38f;
+            mx = fmaxf(mx, x[e]);
+        }
+        mx = wave_max(mx);
+        float c[4], run = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * lane + e;
+            run += j < V ? expf(x[e] - mx) : 0.f;
+            c[e] = run;                                   // inclusive sums inside my four entries
+        }
+        float incl = run;                                 // inclusive scan of the lanes' totals
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        const float total = __shfl(incl, 63, 64), before = incl - run;
+        const unsigned long long r = mix64(mix64(seed ^ ((unsigned long long)b << 32)) + (unsigned long long)t);
+        const float u = (float)(r >> 40) * (1.0f / 16777216.0f) * total;     // 24 uniform bits in [0, 1)
+        int pick = V - 1;                                 // (u * total == total cannot happen; the last entry is the guard)
+#pragma unroll
+        for (int e = 3; e >= 0; --e)
+            if (4 * lane + e < V && before + c[e] > u) pick = 4 * lane + e;
+        // first entry over the threshold = the smallest qualifying index over the wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pick = min(pick, __shfl_xor(pick, o, 64));
+        cur = pick;
+        if (lane == 0) tokens[(long)b * max_len + t] = cur;
+        if (cur == end_token && fe == max_len) fe = t;
+    }
+    if (lane == 0) first_end[b] = fe;
+}
+
 inline int blocks_for(long n) { return (int)((n + 255) / 256); }
 
 }  // namespace
@@ -444,6 +502,17 @@ extern "C" int arcvae_dec_sample_chain(const int32_t* nxt, int32_t* tokens, int3
     if (!nxt || !tokens || !first_end || B <= 0 || V <= 0 || max_len <= 0) return ARCVAE_ERR_ARG;
     hipLaunchKernelGGL(dec_sample_chain_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, stream, nxt, tokens, first_end,
                        B, V, max_len, end_token);
+    return arcvae_launch_status();
+}
+
+// Categorical sampling walk over the dense logits [B*V, V] of arcvae_dec_forward_dense (see dec_sample_categorical_kernel): an
+// extension beyond the reference (its sampler is greedy, Q9); vocab_size <= 256, temperature > 0.
+extern "C" int arcvae_dec_sample_chain_categorical(const float* logits, int32_t* tokens, int32_t* first_end, int B, int V,
+                                                   int max_len, int end_token, float temperature, unsigned long long seed,
+                                                   hipStream_t stream) {
+    if (!logits || !tokens || !first_end || B <= 0 || V <= 0 || V > 256 || max_len <= 0 || !(temperature > 0.f)) return ARCVAE_ERR_ARG;
+    hipLaunchKernelGGL(dec_sample_categorical_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, logits, tokens, first_end, B, V,
+                       max_len, end_token, 1.0f / temperature, seed);
     return arcvae_launch_status();
 }
 

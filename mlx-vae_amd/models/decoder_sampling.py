@@ -4,7 +4,8 @@ Owns its OWN, never-trained decoder (Q9: not weight-shared with ARCVAE.decoder);
 sampling" is argmax(softmax(logits / T)) = greedy; tokens after EOS are still generated; with
 early stopping the output is cut where every row has emitted EOS.  One dense decoder pass
 (B*V rows) + one table walk replaces the reference's max_length dependent steps and its per-step
-host sync; `load_from_decoder` is an explicit extension to sample from trained weights."""
+host sync; `load_from_decoder` is an explicit extension to sample from trained weights, and `sample=True` the true categorical
+sampling the reference marks TODO (decoder_sampling.py:115-116): an extension with no reference behaviour to match."""
 from __future__ import annotations
 
 import torch
@@ -35,8 +36,14 @@ class MLXAutoregressiveDecoderSampling:
         return {"decoder": self.decoder.parameters()}
 
     def generate_with_temperature(self, z, conditions, max_length: int = 80, temperature: float = 1.0,
-                                  early_stopping: bool = True, use_graph: bool = True) -> torch.Tensor:
-        """[B, t_stop] int32 tokens (models/decoder_sampling.py:48-128).  z is accepted and unused (Q2)."""
+                                  early_stopping: bool = True, use_graph: bool = True, *, sample: bool = False,
+                                  seed: int = 0) -> torch.Tensor:
+        """[B, t_stop] int32 tokens (models/decoder_sampling.py:48-128).  z is accepted and unused (Q2).
+        sample=True (keyword-only extension; the default reproduces the reference's greedy "temperature sampling", Q9): every token is
+        DRAWN from softmax(logits / temperature) -- what decoder_sampling.py:115-116 leaves as a TODO -- with a counter-based
+        generator keyed by (seed, row, step): the same seed returns the same molecules."""
+        if sample:
+            return self._generate_categorical(conditions, max_length, temperature, early_stopping, int(seed))
         dec = self.decoder
         dev = dec.store.device
         cond = as_f32(conditions, dev)
@@ -71,4 +78,26 @@ class MLXAutoregressiveDecoderSampling:
             # max_b(first EOS index) + 1 tokens; one host read replaces its per-step mx.all() sync
             t_stop = int(st["first_end"].max().item()) + 1
             tokens = tokens[:, :min(t_stop, max_length)]
+        return tokens.clone()
+
+    def _generate_categorical(self, conditions, max_length: int, temperature: float, early_stopping: bool, seed: int) -> torch.Tensor:
+        """One dense decoder pass (raw logits of all B*V (row, token) pairs), then arcvae_dec_sample_chain_categorical: a wave per
+        row walks start token -> sampled token -> ... through the table of distributions.  Eager launches (the seed is a launch
+        argument; the greedy path's captured pass is untouched)."""
+        import ctypes as C
+        if not temperature > 0.0:
+            raise ValueError("temperature must be > 0 for categorical sampling")
+        dec = self.decoder
+        dev = dec.store.device
+        cond = as_f32(conditions, dev)
+        B = cond.shape[0]
+        ws = dec.workspace(B, max_length)
+        ws.cond.copy_(cond.reshape(B, dec.num_conditions))
+        tokens = torch.zeros(B, max_length, dtype=torch.int32, device=dev)
+        first_end = torch.zeros(B, dtype=torch.int32, device=dev)
+        E.decoder_forward_dense(dec.store, ws, dec.dims, mode=0, keep_gpre=False, alone=True)
+        call("arcvae_dec_sample_chain_categorical", ptr(ws.logits), ptr(tokens), ptr(first_end), B, dec.vocab_size, max_length,
+             dec.end_token, float(temperature), C.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), stream_ptr())
+        if early_stopping:
+            tokens = tokens[:, :min(int(first_end.max().item()) + 1, max_length)]
         return tokens.clone()

@@ -31,12 +31,14 @@ class ARCVAE:
                               coins=coins)
         return logits, mu, logvar, z
 
-    def generate(self, batch_size: int, conditions, max_length: int = 80, temperature: float = 1.0) -> torch.Tensor:
-        """models/vae.py:101-131: z ~ N(0,I) (unused downstream, Q2) -> greedy sampler."""
+    def generate(self, batch_size: int, conditions, max_length: int = 80, temperature: float = 1.0, *, sample: bool = False,
+                 seed: int = 0) -> torch.Tensor:
+        """models/vae.py:101-131: z ~ N(0,I) (unused downstream, Q2) -> greedy sampler.  sample / seed (keyword-only extension):
+        true categorical sampling instead of the reference's argmax, see MLXAutoregressiveDecoderSampling."""
         dev = self.decoder_sampling.decoder.store.device
         z = torch.randn(batch_size, self.latent_dim, device=dev)
         return self.decoder_sampling.generate_with_temperature(z, conditions, max_length=max_length,
-                                                               temperature=temperature)
+                                                               temperature=temperature, sample=sample, seed=seed)
 
     def parameters(self):
         return {"encoder": self.encoder.parameters(), "decoder": self.decoder.parameters(),

@@ -36,7 +36,7 @@ def _ctype_of(decl: str):
     if "*" in ty or ty == "arcvae_stream_t":
         return ctypes.c_void_p
     return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
-            "unsigned": ctypes.c_uint, "unsignedint": ctypes.c_uint}[ty]
+            "unsigned": ctypes.c_uint, "unsignedint": ctypes.c_uint, "unsignedlonglong": ctypes.c_ulonglong}[ty]
 
 
 def test_header_declares_the_path():
