@@ -23,7 +23,8 @@ dbs = [torch.zeros(G, **f32) for l in range(L)]
 pwx, _a = ptr_array(dwx); pwh, _b = ptr_array(dwh); pbs, _c = ptr_array(dbs)
 def call(parts, t_lo, t_hi):
     rc = lib.arcvae_enc_lstm_wgrad(ptr(x_tb), ptr(emb), ptr(wx0), ptr(hseq), ptr(dG), ptr(dtab), ptr(onehot), ptr(demb), pwx, pwh, pbs,
-                                   B, T, V, E, H, L, t_lo, t_hi, 0, 0, parts, ptr(hpl), ptr(gpl), stream_ptr())
+                                   B, T, V, E, H, L, t_lo, t_hi, 0, 0, parts, ptr(hpl), ptr(gpl),
+                                   (C.c_long * 4)(hpl.numel(), gpl.numel(), 0, 0), stream_ptr())
     assert rc == 0, rc
 flops = 2.0 * nT * B * G * H * (2 * L - 1)
 for name, parts in (("planes", 1 | 16 | 2048), ("three-piece tile GEMM (f32 sources)", 1 | 16 | 1024)):

@@ -21,9 +21,9 @@ for _ in range(10): eng.run_step(ws, 2e-4, True)
 torch.cuda.synchronize()
 orig = E.SegmentRunner.__call__
 marks = []
-def timed(self, key, fn, stream):
+def timed(self, key, fn, stream, **kw):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(stream); orig(self, key, fn, stream); e1.record(stream)
+    e0.record(stream); orig(self, key, fn, stream, **kw); e1.record(stream)
     marks.append((key, e0, e1))
 E.SegmentRunner.__call__ = timed
 acc = collections.OrderedDict(); spans = []

@@ -98,9 +98,9 @@ wx, _k1 = E._layer_ptrs(enc, L, "Wx", skip0=True)
 wh, _k2 = E._layer_ptrs(enc, L, "Wh")
 bs, _k3 = E._layer_ptrs(enc, L, "bias", skip0=True)
 alone("forward sweep", lambda: E.call("arcvae_enc_lstm_forward", E.ptr(ws.x_tb), E.ptr(ws.table0), wx, wh, bs, E.ptr(ws.hseq),
-      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, 0, None, E.ptr(ws.trace_fwd), E.stream_ptr()), nf, 0)
+      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, 0, E._caps(ws), None, E.ptr(ws.trace_fwd), E.stream_ptr()), nf, 0)
 alone("BPTT sweep", lambda: E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * H,
-      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, None, None, E.ptr(ws.trace_bwd), E.stream_ptr()), nb, cap // 2)
+      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, E._caps(ws), None, None, E.ptr(ws.trace_bwd), E.stream_ptr()), nb, cap // 2)
 
 # ---- hypothesis checks -------------------------------------------------------------------------------
 big = torch.empty(160 * 1024 * 1024, dtype=torch.float32, device=dev)  # 640 MB: evicts the 256 MB Infinity Cache
@@ -116,9 +116,9 @@ def alone_cold(name, fn, n, off):
     a = buf.cpu().numpy().reshape(cap, 2).astype(np.float64)[off:off + n] / 100.0
     stats(name + " ALONE after a 640 MB write (Infinity Cache evicted)", a - a[0, 0])
 alone_cold("forward sweep", lambda: E.call("arcvae_enc_lstm_forward", E.ptr(ws.x_tb), E.ptr(ws.table0), wx, wh, bs, E.ptr(ws.hseq),
-      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, 0, None, E.ptr(ws.trace_fwd), E.stream_ptr()), nf, 0)
+      E.ptr(ws.hseq_t), E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.wt), E.ptr(ws.wT), B, T, V, H, L, 0, E._caps(ws), None, E.ptr(ws.trace_fwd), E.stream_ptr()), nf, 0)
 alone_cold("BPTT sweep", lambda: E.call("arcvae_enc_lstm_backward", wx, wh, E.ptr(ws.cseq), E.ptr(ws.gseq), E.ptr(ws.dcomb), 2 * H,
-      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, None, None, E.ptr(ws.trace_bwd), E.stream_ptr()), nb, cap // 2)
+      E.ptr(ws.dG), E.ptr(ws.dG_t), E.ptr(ws.dcs), E.ptr(ws.dxs), E.ptr(ws.wT), B, T, H, L, 0, nb, 0, E._caps(ws), None, None, E.ptr(ws.trace_bwd), E.stream_ptr()), nb, cap // 2)
 
 # the engine's own forward segment, replayed with nothing else in flight
 run = E.SegmentRunner(True)
