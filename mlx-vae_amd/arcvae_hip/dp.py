@@ -211,12 +211,39 @@ class EngineOps:
 
     def warm_up(self, group) -> None:
         """First collective of a communicator (channel / IPC set-up: seconds on 8 GPUs) outside the step, on the stream
-        that will use it."""
+        that will use it -- and, where the heads' bucket is to be reduced behind a device-side gate, a dry run of exactly that
+        construction (round 4): [gate on side] [all-reduce on side] released from aux.  If the backend ran the collective on a
+        stream of its own that shares a hardware queue with aux, aux's release would sit behind the collective's wait for the gate
+        -- the gate would expire.  Found here in a few milliseconds (bounded spin), on every rank, the early heads reduce is then
+        switched off for this driver (round 3's order) instead of costing the step its stream order."""
         if dist.is_initialized() and dist.get_backend() == "nccl":
             with torch.cuda.stream(self.eng.side):
                 t = torch.zeros(1024, dtype=torch.float32, device=self.eng.device)
                 dist.all_reduce(t, group=group)
             torch.cuda.synchronize()
+            if self.heads_early:
+                ok = self._probe_reduce_behind_gate(group)
+                self.heads_early = agree_all(ok, self.group, self.eng.device)
+                if not self.heads_early:
+                    print("[arcvae_hip] a collective behind a device-side gate on the side stream does not get released from aux "
+                          "on this setup: the encoder heads' bucket is reduced with the LSTM bucket after the join")
+
+    def _probe_reduce_behind_gate(self, group) -> bool:
+        eng, g = self.eng, self.eng.gates
+        torch.cuda.synchronize()
+        g.mem[g.PROBE * 32] = 0
+        before = g.errors()
+        t = torch.zeros(1024, dtype=torch.float32, device=eng.device)
+        with torch.cuda.stream(eng.side):
+            call("arcvae_gate_wait", g.word(g.PROBE), C.c_void_p(0), 0, 1, 0, 100 * g.SHORT, g.word(g.ERR), stream_ptr())
+            dist.all_reduce(t, group=group)
+        with torch.cuda.stream(eng.aux):
+            call("arcvae_gate_set", g.word(g.PROBE), 1, 0, stream_ptr())
+        torch.cuda.synchronize()
+        ok = g.errors() == before
+        g.mem[g.ERR * 32] = before
+        torch.cuda.synchronize()
+        return ok
 
     def _make_bucket(self) -> None:
         """One contiguous gradient bucket [enc.grad | dec.grad | CE sum]; recorded segments hold the old pointers,
