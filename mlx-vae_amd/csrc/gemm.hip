@@ -1220,11 +1220,14 @@ struct PlaneTN {
 struct PlaneTNGroup {
     PlaneTN p[ARCVAE_PLANE_GROUP_MAX];
     int n, M, N, rows, ldc, z;     // z = K slices per problem (atomic accumulation when > 1)
-    int dbg;                       // timing experiments only (ARCVAE_PLANE_DEBUG): 1 no MFMAs, 2 no fragment reads either, 4 no LDS-DMA in the loop
 };
 typedef short s16x4_g __attribute__((ext_vector_type(4)));
 struct PlaneFrag { s16x4_g lo, hi; };
 namespace {
+// DBG: timing experiments only (ARCVAE_PLANE_DEBUG, tools/r4_planes_knobs.sh): 1 no products, 2 no fragment reads either, 4 no LDS-DMA
+// in the loop.  A template parameter since round 4: as run-time branches they cut the K-step into one basic block per column tile,
+// and the compiler could not put a tile's fragment reads under the previous tile's products.
+template <int DBG>
 __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
     extern __shared__ __attribute__((aligned(16))) char pl_smem[];     // [3 stages][24 pieces: (operand, plane, column block)][32 rows][64 B]
     constexpr int STAGE = 24 * 2048;
@@ -1349,38 +1352,62 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");       // (compiler fence: no LDS read of this K-step may be scheduled above the barrier)
-        if (loader && ks + 2 < kend && !(g.dbg & 4)) issue(ks + 2, cur == 0 ? 2 : cur - 1);         // (the stage read at ks - 1)
-        if (!loader && active && !(g.dbg & 2)) {
-            // A fragments of the K-step stay in registers (48); the B fragments come one 16-column tile at a time (12): the
-            // whole set would not fit beside the accumulators at two waves per SIMD
-            bf16x8_t fa[3][4];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) fa[pl][tt] = frag(cur, 0, pl, tt);
-            if (rider) {
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl)       // lo, mid, hi: small pieces first
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pl][i], ones, accb[i], 0, 0, 0);
-            }
+        if (loader && ks + 2 < kend && !(DBG & 4)) issue(ks + 2, cur == 0 ? 2 : cur - 1);         // (the stage read at ks - 1)
+        if (!loader && active && !(DBG & 2)) {
+            // A fragments of the K-step stay in registers (48); the B fragments of ONE 16-column tile (12) are read while the
+            // products of the tile before it run (two sets).  Read order = use order: the K-step's first product waits for 10 reads,
+            // not for 30.  (Round 4: reads and products of a K-step used to alternate -- reads, drain, 24 products, reads ... --
+            // 1.29 us per K-step without any LDS-DMA against 0.64 us of products.)
+            bf16x8_t fa[3][4], fb[2][3];
+#define PLANE_LOADA(PL) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) fa[PL][tt] = frag(cur, 0, PL, tt);
+            PLANE_LOADA(2) fb[0][0] = frag(cur, 1, 0, 0);
+            PLANE_LOADA(0) fb[0][2] = frag(cur, 1, 2, 0);
+            PLANE_LOADA(1) fb[0][1] = frag(cur, 1, 1, 0);
+#undef PLANE_LOADA
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bf16x8_t fb[3];
+                const int b = j & 1;
+                if (j < 3) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) fb[pl] = frag(cur, 1, pl, j);
-                if (g.dbg & 1) {      // (timing experiment: keep the reads alive without the products)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) { acc[pl][j][0] += (float)fa[pl][j][0]; acc[pl][j][1] += (float)fb[pl][0]; }
-                    continue;
+                    for (int pl = 0; pl < 3; ++pl) fb[b ^ 1][pl] = frag(cur, 1, pl, j + 1);
                 }
-                // the six products of weight >= 2^-16, small ones first (pieces: 0 hi, 1 mid, 2 lo)
+                if constexpr ((DBG & 1) != 0) {      // (timing experiment: keep the reads alive without the products)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { acc[pl][j][0] += (float)fa[pl][j][0]; acc[pl][j][1] += (float)fb[b][pl][0]; }
+                } else {
+                    // the six products of weight >= 2^-16, small ones first (pieces: 0 hi, 1 mid, 2 lo)
 #define PLANE_S3(PA, PB)                                                                                         \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][i], fb[PB], acc[i][j], 0, 0, 0);
-                PLANE_S3(0, 2) PLANE_S3(2, 0) PLANE_S3(1, 1) PLANE_S3(0, 1) PLANE_S3(1, 0) PLANE_S3(0, 0)
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][i], fb[b][PB], acc[i][j], 0, 0, 0);
+                    PLANE_S3(2, 0) PLANE_S3(0, 2) PLANE_S3(1, 1) PLANE_S3(0, 1) PLANE_S3(1, 0) PLANE_S3(0, 0)
 #undef PLANE_S3
+                }
+            }
+            if constexpr ((DBG & 1) == 0) {
+                // The order asked of the scheduler for this block (48 reads, 96 products): the 10 reads of the first product, then
+                // the other 20 reads of tile 0 under its first 8 products, then the 6 reads of the next tile under the first 12-18 products of a tile.
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                for (int jj = 1; jj < 3; ++jj) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+                if (rider) {
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl)       // lo, mid, hi: small pieces first
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pl][i], ones, accb[i], 0, 0, 0);
+                }
             }
         }
         cur = cur == 2 ? 0 : cur + 1;
@@ -1407,6 +1434,187 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
             }
         }
 }
+
+// ---- round 4: the same GEMM with TWO consuming waves per SIMD -------------------------------------------------------------------
+// What `wgrad_planes_kernel` above costs per K-step (tools/r4_planes_knobs.sh, configs[2] chunk shape, 1024 K-steps per CU and call):
+// 1.38 us in all; products + fragment reads alone 1.12; the LDS-DMA alone 0.80 -- against 1536 matrix cycles = 0.64 us at 2.4 GHz,
+// ≈ 0.8 us at the ≈ 1.9 GHz the chip holds in a bf16 MFMA loop on random data (MI355X_MICROARCH.md, DVFS give-back).  One consuming
+// wave per SIMD exposes every bubble of its own (the barrier, the first reads of a K-step) to the matrix pipe, and its SIMD-mate, the
+// loader, spends 100-185 cycles of issue per LDS-DMA piece beside it.  Here: the 128 x 128 tile on EIGHT consuming waves (64 m x 32 n
+// each, two per SIMD: one's bubbles sit under the other's products) and NLOAD = 4 or 8 loader waves (12 or 6 pieces each per K-step);
+// the LDS image, the three stages and the ring's waits are those of the kernel above.  Products by A plane -- lo, mid, hi -- so that
+// an A plane's fragments die with its phase (<= 128 registers at four waves per SIMD); the bias rider (the product with a column of
+// ones) is dealt over the four waves of a row of the tile, one 16-row tile of m each.
+template <int NLOAD, int DBG>
+__global__ __launch_bounds__(64 * (8 + NLOAD)) void wgrad_planes2_kernel(PlaneTNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];     // [3 stages][24 pieces: (operand, plane, column block)][32 rows][64 B]
+    constexpr int STAGE = 24 * 2048;
+    constexpr int PPW = 24 / NLOAD;                                     // pieces per loader wave and K-step (two LDS-DMA instructions each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by, bz;                                                     // XCD-contiguous block order, as above
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+        const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned xcd = id & 7, slot = id >> 3, q = n >> 3, r = n & 7;
+        const unsigned nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        bx = __builtin_amdgcn_readfirstlane((int)(nid % gx));
+        by = __builtin_amdgcn_readfirstlane((int)((nid / gx) % gy));
+        bz = __builtin_amdgcn_readfirstlane((int)(nid / (gx * gy)));
+    }
+    const int prob = __builtin_amdgcn_readfirstlane(bz / g.z), slice = bz - prob * g.z;
+    PlaneTN p;
+    {
+        const PlaneTN& q = g.p[prob];
+        auto uni64 = [](unsigned long long v) -> unsigned long long {      // (unsigned halves: see the kernel above)
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+            return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+        };
+        p.A = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.A)));
+        p.B = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.B)));
+        p.C = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.C)));
+        p.colsum = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.colsum)));
+        p.tA0 = __builtin_amdgcn_readfirstlane(q.tA0); p.tB0 = __builtin_amdgcn_readfirstlane(q.tB0);
+        p.ksteps = __builtin_amdgcn_readfirstlane(q.ksteps);
+    }
+    const int gM = g.M, gN = g.N, grows = g.rows;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int rb = grows >> 5;
+    const int per = (p.ksteps + g.z - 1) / g.z;
+    const int kbeg = slice * per, kend = min(p.ksteps, kbeg + per);
+    if (kbeg >= kend) return;                                           // block-uniform
+    const long planeA = (long)grows * gM, planeB = (long)grows * gN;
+    const bool loader = wave >= 8;
+    auto issue = [&](int ks, int stage) {
+        const int t = ks / rb, b0 = (ks - t * rb) << 5;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int pc = PPW * (wave - 8) + q, op = pc >= 12 ? 1 : 0, pl = (pc - 12 * op) >> 2, cb = pc & 3;
+            const int colblock = min(((op ? n0 : m0) >> 5) + cb, ((op ? gN : gM) >> 5) - 1);
+            const __bf16* src = op ? p.B + ((long)(p.tB0 + t) * 3 + pl) * planeB + ((long)colblock * grows + b0) * 32
+                                   : p.A + ((long)(p.tA0 + t) * 3 + pl) * planeA + ((long)colblock * grows + b0) * 32;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int row = 16 * hf + (lane >> 2), oct = (lane & 3) ^ (((row >> 3) & 1) << 1);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) char*)(pl_smem + stage * STAGE + pc * 2048 + hf * 1024));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src + row * 32 + oct * 8), "s"(dst) : "memory");
+            }
+        }
+    };
+    const int wm = (wave >> 2) & 1, wn = wave & 3;
+    const bool active = n0 + 32 * wn < gN;                               // wave-uniform (N % 64 == 0: a wave's 32 columns are in or out)
+    const int kq = lane >> 4, kp = (lane & 15) >> 2, a4 = lane & 3;
+    // 16-column group c16 of the operand's 128 columns in this block: A (m) 4 wm + tt, B (n) 2 wn + tt
+    auto frag = [&](int stage, int op, int pl, int tt) -> bf16x8_t {
+        const int c16 = op ? 2 * wn + tt : 4 * wm + tt, cb = c16 >> 1, tt2 = c16 & 1;
+        const char* base = pl_smem + stage * STAGE + ((op * 3 + pl) * 4 + cb) * 2048;
+        const int oct = (2 * tt2 + (a4 >> 1)) ^ ((kq & 1) << 1);
+        const char* q0 = base + (8 * kq + kp) * 64 + oct * 16 + (a4 & 1) * 8;
+        PlaneFrag f;
+        f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0));
+        f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0 + 4 * 64));
+        return __builtin_bit_cast(bf16x8_t, f);
+    };
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool rider = !loader && p.colsum != nullptr && n0 == 0;        // block-uniform among the consuming waves
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};                              // colsum of m tile i = wn of my 64 rows
+    bf16x8_t ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (__bf16)1.0f;
+    constexpr int NW = 2 * PPW;                                          // LDS-DMA instructions per loader wave and K-step
+    if (loader) {
+        issue(kbeg, 0);
+        if (kbeg + 1 < kend) issue(kbeg + 1, 1);
+    }
+    int cur = 0;
+    for (int ks = kbeg; ks < kend; ++ks) {
+        if (loader) {
+            if (ks + 1 < kend) {
+                if constexpr (NW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (every fragment read of K-step ks - 1 has returned: ADVICE r3)
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (loader && ks + 2 < kend && !(DBG & 4)) issue(ks + 2, cur == 0 ? 2 : cur - 1);         // (the stage read at ks - 1)
+        if (!loader && active && !(DBG & 2)) {
+            bf16x8_t fa[3][4], fb[3][2];
+#define P2_LOADA(PL) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) fa[PL][tt] = frag(cur, 0, PL, tt);
+#define P2_LOADB(PL) _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) fb[PL][tt] = frag(cur, 1, PL, tt);
+            P2_LOADA(2) P2_LOADB(0)
+            P2_LOADA(1) P2_LOADB(1)
+            P2_LOADA(0) P2_LOADB(2)
+#undef P2_LOADA
+#undef P2_LOADB
+            if constexpr ((DBG & 1) != 0) {      // (timing experiment: keep the reads alive without the products)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { acc[pl][j][0] += (float)fa[pl][j][0] + (float)fa[pl][j + 2][0]; acc[pl][j][1] += (float)fb[pl][j][0]; }
+            } else {
+                // the six products of weight >= 2^-16 (pieces: 0 hi, 1 mid, 2 lo), by A plane: lo, mid, hi
+#define P2_S3(PA, PB)                                                                                            \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
+                P2_S3(2, 0) P2_S3(1, 1) P2_S3(1, 0) P2_S3(0, 2) P2_S3(0, 1) P2_S3(0, 0)
+#undef P2_S3
+                // asked of the scheduler (36 reads, 48 products): the 12 reads of the first product; the next 12 under its 8
+                // products; the last 12 under the first 12 of the mid plane's 16
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 28, 0);
+            }
+        }
+        if constexpr ((DBG & 3) == 0) {
+            if (rider) {
+                // (every consuming wave of the block, also one whose 32 columns lie beyond N; its own reads of the three fragments:
+                // kept in registers from their phases they would hold 48 registers to the end of the K-step)
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl) {
+                    const bf16x8_t f = frag(cur, 0, pl, wn);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, ones, accb, 0, 0, 0);
+                }
+            }
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    if (loader) return;
+    if (rider && (lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + m0 + 64 * wm + 16 * wn + 4 * (lane >> 4) + r, accb[r]);
+    }
+    if (!active) return;
+    // D[m = 4 (lane >> 4) + r][n = lane & 15] of tile (i, j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * wn + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + r;
+                float* c = p.C + (long)m * g.ldc + n;
+                if (g.z > 1) atomicAdd(c, acc[i][j][r]);
+                else *c += acc[i][j][r];
+            }
+        }
+}
 }  // namespace
 
 // dW_i[M, N] += dG_i^T . h_i over the time steps [t, t + nT) of each problem, operands = the sweeps' three-plane copies (all
@@ -1417,7 +1625,7 @@ int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* 
     if (n <= 0 || n > ARCVAE_PLANE_GROUP_MAX || M <= 0 || N <= 0 || (M % 128) || (N % 64) || rows <= 0 || (rows % 32) || ldc < N)
         return ARCVAE_ERR_ARG;
     PlaneTNGroup g;
-    g.n = n; g.M = M; g.N = N; g.rows = rows; g.ldc = ldc; g.dbg = arcvae_env_int("ARCVAE_PLANE_DEBUG", 0);
+    g.n = n; g.M = M; g.N = N; g.rows = rows; g.ldc = ldc;
     int kmax = 0;
     for (int i = 0; i < n; ++i) {
         if (!A[i] || !B[i] || !C[i] || nT[i] <= 0 || tA0[i] < 0 || tB0[i] < 0) return ARCVAE_ERR_ARG;
@@ -1431,9 +1639,31 @@ int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* 
     const int tiles = (M / 128) * ceil_div(N, 128);
     static const int target = arcvae_env_int("ARCVAE_PLANE_BLOCKS", 448);     // blocks wanted per launch
     g.z = max(1, min(ceil_div(target, tiles * n), kmax / 16));                // at least 16 K-steps per slice
+    const dim3 grid(ceil_div(N, 128), M / 128, n * g.z);
+    const size_t lds = 3 * 24 * 2048;
     // (> 64 KB of dynamic LDS has to be allowed per kernel; set on every call: idempotent, no host state kept)
-    (void)hipFuncSetAttribute((const void*)wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24 * 2048);
-    hipLaunchKernelGGL(wgrad_planes_kernel, dim3(ceil_div(N, 128), M / 128, n * g.z), dim3(512), 3 * 24 * 2048, stream, g);
+#define PLANE_LAUNCH(D)                                                                                              \
+    { if (form == 0) {                                                                                               \
+        (void)hipFuncSetAttribute((const void*)wgrad_planes_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(wgrad_planes_kernel<D>, grid, dim3(512), lds, stream, g);                                \
+      } else if (form == 1) {                                                                                        \
+        (void)hipFuncSetAttribute((const void*)wgrad_planes2_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((wgrad_planes2_kernel<4, D>), grid, dim3(768), lds, stream, g);                          \
+      } else {                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)wgrad_planes2_kernel<8, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((wgrad_planes2_kernel<8, D>), grid, dim3(1024), lds, stream, g);                         \
+      } }
+    // ARCVAE_PLANE_FORM: 0 one consuming wave per SIMD + 4 loader waves (round 3), 1 two consuming waves per SIMD + 4 loaders, 2 + 8 loaders
+    static const int form = arcvae_env_int("ARCVAE_PLANE_FORM", 0);
+    switch (arcvae_env_int("ARCVAE_PLANE_DEBUG", 0)) {      // (timing experiments; results are wrong for anything but 0)
+        case 1: PLANE_LAUNCH(1) break;
+        case 2: PLANE_LAUNCH(2) break;
+        case 4: PLANE_LAUNCH(4) break;
+        case 5: PLANE_LAUNCH(5) break;
+        case 6: PLANE_LAUNCH(6) break;
+        default: PLANE_LAUNCH(0)
+    }
+#undef PLANE_LAUNCH
     return arcvae_launch_status();
 }
 
