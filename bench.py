@@ -70,6 +70,33 @@ def executed_flops_per_step(V, E, H, Z, C, L, T, B):
     return float(enc_f + heads_f + dec_f + enc_b + heads_b + dec_b)
 
 
+_VENDOR_BF16 = {}
+
+
+def vendor_bf16_gemm_tflops(torch, dev) -> float:
+    """What the vendor library's bf16 GEMM (hipBLASLt through torch.matmul) sustains on THIS device on random operands, 8192^3:
+    the practical ceiling of the bf16 matrix pipe under load (the chip lowers its clock in a dense MFMA loop on random data:
+    1.27-1.37 PFLOP/s measured in round 4 against the nominal 2.5) -- the second denominator of the three-piece legs."""
+    if "v" not in _VENDOR_BF16:
+        n = 8192
+        a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+        for _ in range(3):
+            c = a @ b
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            c = a @ b
+        e1.record()
+        torch.cuda.synchronize()
+        _VENDOR_BF16["v"] = 2.0 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        del a, b, c
+        torch.cuda.empty_cache()
+    return _VENDOR_BF16["v"]
+
+
 def sampler_flops(V, E, H, C, L, rows):
     """Contractions the greedy sampler executes for one batch of `rows` molecules, whatever max_length: the decoder is
     stateless (Q1/Q2), so ONE dense pass over the rows x V (row, token) pairs decides every step of every row."""
@@ -562,6 +589,10 @@ def main(argv=None):
                                           else "per-step launches (lstm_bwd_step*/tile kernels)")}
                 if getattr(ws2, "planes", False):   # the leg's contractions run in the three-piece form (tile regime)
                     strong["step_executed_frac_of_bf16_pipe"] = 6.0 * strong["step_tflops_executed_per_gpu"] / 2500.0
+                    if rank == 0:
+                        strong["vendor_bf16_gemm_tflops"] = vendor_bf16_gemm_tflops(torch, dev)
+                        strong["step_executed_frac_of_vendor_bf16_gemm"] = (6.0 * strong["step_tflops_executed_per_gpu"]
+                                                                            / strong["vendor_bf16_gemm_tflops"])
                 if comm2 is not None:
                     strong["comm"] = comm2
                 if rank == 0 and not args.no_roofline:
@@ -706,6 +737,10 @@ def main(argv=None):
                     # every large contraction of this leg runs in the three-piece form (sweeps, plane GEMMs, dense decoder stack):
                     # the bf16 products issued per second against the pipe they issue on
                     legs[prec]["executed_frac_of_bf16_pipe"] = 6.0 * legs[prec]["step_tflops_executed"] / 2500.0
+                    # ... and against what the vendor's bf16 GEMM sustains on this device on random data (measured here)
+                    legs[prec]["vendor_bf16_gemm_tflops"] = vendor_bf16_gemm_tflops(torch, dev)
+                    legs[prec]["executed_frac_of_vendor_bf16_gemm"] = (6.0 * legs[prec]["step_tflops_executed"]
+                                                                       / legs[prec]["vendor_bf16_gemm_tflops"])
                     if not args.no_roofline:
                         legs[prec]["roofline"] = roofline_probe(eng4, ws4, torch)   # the MFMA-bound regime's dominant kernel, live
                 else:
@@ -873,9 +908,12 @@ def roofline_probe(eng, ws, torch):
         # ("98 % of the f32 peak" is a ratio against a pipe these kernels do not run on)
         out["executed_tflops_on_bf16_pipe"] = 6.0 * ach
         out["executed_frac_of_bf16_pipe"] = 6.0 * ach / 2500.0
+        out["vendor_bf16_gemm_tflops"] = vendor_bf16_gemm_tflops(torch, torch.device("cuda", torch.cuda.current_device()))
+        out["executed_frac_of_vendor_bf16_gemm"] = 6.0 * ach / out["vendor_bf16_gemm_tflops"]
         out["pipe_note"] = ("three-piece form: six v_mfma_f32_16x16x32_bf16 products per f32 product -- `achieved` / `frac` price the "
                             "f32-equivalent FLOP against the f32 MFMA peak (SURVEY 8(d)); executed_* price the bf16 products "
-                            "actually issued against the dense bf16 peak (2.5 PFLOP/s)")
+                            "actually issued against the dense bf16 peak (2.5 PFLOP/s) and against the vendor library's bf16 GEMM "
+                            "(8192^3, random operands) measured on this device in this run")
     return out
 
 

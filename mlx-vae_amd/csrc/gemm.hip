@@ -16,6 +16,11 @@
 //   * skinny kernel (skinny.h): 16x16 tile per block, K split over the 4 waves -- used when M is
 //     a minibatch (<= 256 rows) and the op is on the step's critical path.
 #include "ops.h"
+#ifdef ARCVAE_PLANE_CLOCK
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#endif
 #include "skinny.h"
 
 namespace {
@@ -1230,6 +1235,12 @@ namespace {
 // DBG: timing experiments only (ARCVAE_PLANE_DEBUG, tools/r4_planes_knobs.sh): 1 no products, 2 no fragment reads either, 4 no LDS-DMA
 // in the loop.  A template parameter since round 4: as run-time branches they cut the K-step into one basic block per column tile,
 // and the compiler could not put a tile's fragment reads under the previous tile's products.
+// Where this loop stands (round 4): 1.27 us per K-step at the 1.77-1.84 GHz the chip holds in it (diagnostic build
+// -DARCVAE_PLANE_CLOCK) = 1.02 PFLOP/s of bf16 products, against 1.27-1.37 PFLOP/s of the vendor library's large bf16 GEMM on random
+// data on the same box (tools/r4_bf16_peak.py) and 0.59 on a GEMM of this call's shape.  Built, parity-green and dropped (commit
+// history): two consuming waves per SIMD with 4 or 8 loader waves (1.46 / 1.57 ms per call against 1.42), and the ring handed over
+// through LDS flags instead of the block barrier, the next K-step's first reads ahead of the last tile's products (1.53 ms) -- the
+// loop is bound by the matrix pipe at the rate the chip sustains, not by its bubbles.
 template <int DBG>
 __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
     extern __shared__ __attribute__((aligned(16))) char pl_smem[];     // [3 stages][24 pieces: (operand, plane, column block)][32 rows][64 B]
@@ -1448,444 +1459,6 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(PlaneTNGroup g) {
         }
 }
 
-// ---- round 4: the same GEMM with TWO consuming waves per SIMD -------------------------------------------------------------------
-// What `wgrad_planes_kernel` above costs per K-step (tools/r4_planes_knobs.sh, configs[2] chunk shape, 1024 K-steps per CU and call):
-// 1.38 us in all; products + fragment reads alone 1.12; the LDS-DMA alone 0.80 -- against 1536 matrix cycles = 0.64 us at 2.4 GHz,
-// ≈ 0.8 us at the ≈ 1.9 GHz the chip holds in a bf16 MFMA loop on random data (MI355X_MICROARCH.md, DVFS give-back).  One consuming
-// wave per SIMD exposes every bubble of its own (the barrier, the first reads of a K-step) to the matrix pipe, and its SIMD-mate, the
-// loader, spends 100-185 cycles of issue per LDS-DMA piece beside it.  Here: the 128 x 128 tile on EIGHT consuming waves (64 m x 32 n
-// each, two per SIMD: one's bubbles sit under the other's products) and NLOAD = 4 or 8 loader waves (12 or 6 pieces each per K-step);
-// the LDS image, the three stages and the ring's waits are those of the kernel above.  Products by A plane -- lo, mid, hi -- so that
-// an A plane's fragments die with its phase (<= 128 registers at four waves per SIMD); the bias rider (the product with a column of
-// ones) is dealt over the four waves of a row of the tile, one 16-row tile of m each.
-template <int NLOAD, int DBG>
-__global__ __launch_bounds__(64 * (8 + NLOAD)) void wgrad_planes2_kernel(PlaneTNGroup g) {
-    extern __shared__ __attribute__((aligned(16))) char pl_smem[];     // [3 stages][24 pieces: (operand, plane, column block)][32 rows][64 B]
-    constexpr int STAGE = 24 * 2048;
-    constexpr int PPW = 24 / NLOAD;                                     // pieces per loader wave and K-step (two LDS-DMA instructions each)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bx, by, bz;                                                     // XCD-contiguous block order, as above
-    {
-        const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
-        const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        const unsigned xcd = id & 7, slot = id >> 3, q = n >> 3, r = n & 7;
-        const unsigned nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        bx = __builtin_amdgcn_readfirstlane((int)(nid % gx));
-        by = __builtin_amdgcn_readfirstlane((int)((nid / gx) % gy));
-        bz = __builtin_amdgcn_readfirstlane((int)(nid / (gx * gy)));
-    }
-    const int prob = __builtin_amdgcn_readfirstlane(bz / g.z), slice = bz - prob * g.z;
-    PlaneTN p;
-    {
-        const PlaneTN& q = g.p[prob];
-        auto uni64 = [](unsigned long long v) -> unsigned long long {      // (unsigned halves: see the kernel above)
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-            return ((unsigned long long)hi << 32) | (unsigned long long)lo;
-        };
-        p.A = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.A)));
-        p.B = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.B)));
-        p.C = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.C)));
-        p.colsum = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.colsum)));
-        p.tA0 = __builtin_amdgcn_readfirstlane(q.tA0); p.tB0 = __builtin_amdgcn_readfirstlane(q.tB0);
-        p.ksteps = __builtin_amdgcn_readfirstlane(q.ksteps);
-    }
-    const int gM = g.M, gN = g.N, grows = g.rows;
-    const int m0 = by * 128, n0 = bx * 128;
-    const int rb = grows >> 5;
-    const int per = (p.ksteps + g.z - 1) / g.z;
-    const int kbeg = slice * per, kend = min(p.ksteps, kbeg + per);
-    if (kbeg >= kend) return;                                           // block-uniform
-    const long planeA = (long)grows * gM, planeB = (long)grows * gN;
-    const bool loader = wave >= 8;
-    auto issue = [&](int ks, int stage) {
-        const int t = ks / rb, b0 = (ks - t * rb) << 5;
-#pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-            const int pc = PPW * (wave - 8) + q, op = pc >= 12 ? 1 : 0, pl = (pc - 12 * op) >> 2, cb = pc & 3;
-            const int colblock = min(((op ? n0 : m0) >> 5) + cb, ((op ? gN : gM) >> 5) - 1);
-            const __bf16* src = op ? p.B + ((long)(p.tB0 + t) * 3 + pl) * planeB + ((long)colblock * grows + b0) * 32
-                                   : p.A + ((long)(p.tA0 + t) * 3 + pl) * planeA + ((long)colblock * grows + b0) * 32;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int row = 16 * hf + (lane >> 2), oct = (lane & 3) ^ (((row >> 3) & 1) << 1);
-                const unsigned dst = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(size_t)(__attribute__((address_space(3))) char*)(pl_smem + stage * STAGE + pc * 2048 + hf * 1024));
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src + row * 32 + oct * 8), "s"(dst) : "memory");
-            }
-        }
-    };
-    const int wm = (wave >> 2) & 1, wn = wave & 3;
-    const bool active = n0 + 32 * wn < gN;                               // wave-uniform (N % 64 == 0: a wave's 32 columns are in or out)
-    const int kq = lane >> 4, kp = (lane & 15) >> 2, a4 = lane & 3;
-    // 16-column group c16 of the operand's 128 columns in this block: A (m) 4 wm + tt, B (n) 2 wn + tt
-    auto frag = [&](int stage, int op, int pl, int tt) -> bf16x8_t {
-        const int c16 = op ? 2 * wn + tt : 4 * wm + tt, cb = c16 >> 1, tt2 = c16 & 1;
-        const char* base = pl_smem + stage * STAGE + ((op * 3 + pl) * 4 + cb) * 2048;
-        const int oct = (2 * tt2 + (a4 >> 1)) ^ ((kq & 1) << 1);
-        const char* q0 = base + (8 * kq + kp) * 64 + oct * 16 + (a4 & 1) * 8;
-        PlaneFrag f;
-        f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0));
-        f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0 + 4 * 64));
-        return __builtin_bit_cast(bf16x8_t, f);
-    };
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool rider = !loader && p.colsum != nullptr && n0 == 0;        // block-uniform among the consuming waves
-    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};                              // colsum of m tile i = wn of my 64 rows
-    bf16x8_t ones;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) ones[k] = (__bf16)1.0f;
-    constexpr int NW = 2 * PPW;                                          // LDS-DMA instructions per loader wave and K-step
-    if (loader) {
-        issue(kbeg, 0);
-        if (kbeg + 1 < kend) issue(kbeg + 1, 1);
-    }
-    int cur = 0;
-    for (int ks = kbeg; ks < kend; ++ks) {
-        if (loader) {
-            if (ks + 1 < kend) {
-                if constexpr (NW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (every fragment read of K-step ks - 1 has returned: ADVICE r3)
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (loader && ks + 2 < kend && !(DBG & 4)) issue(ks + 2, cur == 0 ? 2 : cur - 1);         // (the stage read at ks - 1)
-        if (!loader && active && !(DBG & 2)) {
-            bf16x8_t fa[3][4], fb[3][2];
-#define P2_LOADA(PL) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) fa[PL][tt] = frag(cur, 0, PL, tt);
-#define P2_LOADB(PL) _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) fb[PL][tt] = frag(cur, 1, PL, tt);
-            P2_LOADA(2) P2_LOADB(0)
-            P2_LOADA(1) P2_LOADB(1)
-            P2_LOADA(0) P2_LOADB(2)
-#undef P2_LOADA
-#undef P2_LOADB
-            if constexpr ((DBG & 1) != 0) {      // (timing experiment: keep the reads alive without the products)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) { acc[pl][j][0] += (float)fa[pl][j][0] + (float)fa[pl][j + 2][0]; acc[pl][j][1] += (float)fb[pl][j][0]; }
-            } else {
-                // the six products of weight >= 2^-16 (pieces: 0 hi, 1 mid, 2 lo), by A plane: lo, mid, hi
-#define P2_S3(PA, PB)                                                                                            \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
-                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0);
-                P2_S3(2, 0) P2_S3(1, 1) P2_S3(1, 0) P2_S3(0, 2) P2_S3(0, 1) P2_S3(0, 0)
-#undef P2_S3
-                // asked of the scheduler (36 reads, 48 products): the 12 reads of the first product; the next 12 under its 8
-                // products; the last 12 under the first 12 of the mid plane's 16
-                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#pragma unroll
-                for (int k = 0; k < 12; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 28, 0);
-            }
-        }
-        if constexpr ((DBG & 3) == 0) {
-            if (rider) {
-                // (every consuming wave of the block, also one whose 32 columns lie beyond N; its own reads of the three fragments:
-                // kept in registers from their phases they would hold 48 registers to the end of the K-step)
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl) {
-                    const bf16x8_t f = frag(cur, 0, pl, wn);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, ones, accb, 0, 0, 0);
-                }
-            }
-        }
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-    if (loader) return;
-    if (rider && (lane & 15) == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + m0 + 64 * wm + 16 * wn + 4 * (lane >> 4) + r, accb[r]);
-    }
-    if (!active) return;
-    // D[m = 4 (lane >> 4) + r][n = lane & 15] of tile (i, j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 32 * wn + 16 * j + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + r;
-                float* c = p.C + (long)m * g.ldc + n;
-                if (g.z > 1) atomicAdd(c, acc[i][j][r]);
-                else *c += acc[i][j][r];
-            }
-        }
-}
-
-// ---- round 4: the ring without a barrier ----------------------------------------------------------------------------------------
-// In-kernel stamps (tools/r4_plane_clock.sh) put the K loop of `wgrad_planes_kernel` at 1.27 us per K-step at the 1.77-1.84 GHz the
-// chip holds there: 2 250 cycles for 1 536 cycles of products.  A third of the loop is the block-wide barrier of every K-step and the
-// reads that can only start behind it.  Same tile, same LDS image, same loader / consumer waves -- but the three stages are handed
-// over through words in LDS: a loader wave publishes `ready[stage][loader] = i + 1` once its pieces of K-step i have landed
-// (counted vmcnt), a consumer publishes `freed[stage][consumer] = i + 1` once every fragment read of K-step i has returned, a
-// loader refills a stage when all four consumers have freed it.  Consumers no longer meet each other, and a K-step's first ten reads
-// (the lo plane of dG, the hi plane of the first h tile) are issued in front of the LAST 24 products of the K-step before, as soon
-// as that stage is ready -- the matrix pipe does not drain at a K-step's boundary.
-// Every spin is bounded and gives the block up through `abort` (results wrong, grid drained); tests/test_kernels_gpu.py has the cases.
-template <int DBG>
-__global__ __launch_bounds__(512) void wgrad_planes_ring_kernel(PlaneTNGroup g) {
-    extern __shared__ __attribute__((aligned(16))) char pl_smem[];     // [3 stages][24 pieces][32 rows][64 B], then 32 sync words
-    constexpr int STAGE = 24 * 2048;
-    unsigned* const sync = reinterpret_cast<unsigned*>(pl_smem + 3 * STAGE);   // ready [3][4] | freed [3][4] | abort
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bx, by, bz;                                                     // XCD-contiguous block order (see wgrad_planes_kernel)
-    {
-        const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
-        const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        const unsigned xcd = id & 7, slot = id >> 3, q = n >> 3, r = n & 7;
-        const unsigned nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        bx = __builtin_amdgcn_readfirstlane((int)(nid % gx));
-        by = __builtin_amdgcn_readfirstlane((int)((nid / gx) % gy));
-        bz = __builtin_amdgcn_readfirstlane((int)(nid / (gx * gy)));
-    }
-    const int prob = __builtin_amdgcn_readfirstlane(bz / g.z), slice = bz - prob * g.z;
-    PlaneTN p;
-    {
-        const PlaneTN& q = g.p[prob];
-        auto uni64 = [](unsigned long long v) -> unsigned long long {      // (unsigned halves: see wgrad_planes_kernel)
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-            return ((unsigned long long)hi << 32) | (unsigned long long)lo;
-        };
-        p.A = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.A)));
-        p.B = reinterpret_cast<const __bf16*>(uni64(reinterpret_cast<unsigned long long>(q.B)));
-        p.C = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.C)));
-        p.colsum = reinterpret_cast<float*>(uni64(reinterpret_cast<unsigned long long>(q.colsum)));
-        p.tA0 = __builtin_amdgcn_readfirstlane(q.tA0); p.tB0 = __builtin_amdgcn_readfirstlane(q.tB0);
-        p.ksteps = __builtin_amdgcn_readfirstlane(q.ksteps);
-    }
-    const int gM = g.M, gN = g.N, grows = g.rows;
-    const int m0 = by * 128, n0 = bx * 128;
-    const int rb = grows >> 5;
-    const int per = (p.ksteps + g.z - 1) / g.z;
-    const int kbeg = slice * per, kend = min(p.ksteps, kbeg + per);
-    if (kbeg >= kend) return;                                           // block-uniform
-    const int nk = kend - kbeg;
-    const long planeA = (long)grows * gM, planeB = (long)grows * gN;
-    const bool loader = wave >= 4;
-    const int wm = (wave >> 1) & 1, wn = wave & 1;
-    const bool active = n0 + 64 * wn < gN;                               // wave-uniform
-    if (tid < 32) {
-        // a consumer whose 64 columns lie beyond N takes no part: its `freed` words read as "always"
-        const bool idle = tid >= 12 && tid < 24 && (n0 + 64 * ((tid - 12) & 1) >= gN);
-        sync[tid] = idle ? 0xffffffffu : 0u;
-    }
-    __syncthreads();
-    constexpr unsigned SPINS = 1u << 22;
-    // all four words of one row of `ready` / `freed` at least `need`?  (lanes 0-3 matter; the load is wave-wide, the answer uniform)
-    auto reached = [&](const unsigned* row, unsigned need) -> bool {
-        const unsigned v = __hip_atomic_load(row + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return __all((int)(v - need) >= 0 || v == 0xffffffffu);
-    };
-    auto wait_for = [&](const unsigned* row, unsigned need) -> bool {
-        unsigned spins = 0;
-        while (!reached(row, need)) {
-            if (++spins > SPINS || __hip_atomic_load(sync + 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                __hip_atomic_store(sync + 24, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return false;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-        return true;
-    };
-
-    if (loader) {
-        const int lw = wave - 4;
-        auto issue = [&](int ks, int stage) {
-            const int t = ks / rb, b0 = (ks - t * rb) << 5;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int pc = 6 * lw + q, op = pc >= 12 ? 1 : 0, pl = (pc - 12 * op) >> 2, cb = pc & 3;
-                const int colblock = min(((op ? n0 : m0) >> 5) + cb, ((op ? gN : gM) >> 5) - 1);
-                const __bf16* src = op ? p.B + ((long)(p.tB0 + t) * 3 + pl) * planeB + ((long)colblock * grows + b0) * 32
-                                       : p.A + ((long)(p.tA0 + t) * 3 + pl) * planeA + ((long)colblock * grows + b0) * 32;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int row = 16 * hf + (lane >> 2), oct = (lane & 3) ^ (((row >> 3) & 1) << 1);
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(
-                        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(pl_smem + stage * STAGE + pc * 2048 + hf * 1024));
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(src + row * 32 + oct * 8), "s"(dst) : "memory");
-                }
-            }
-        };
-        auto publish = [&](int i) {      // my pieces of K-step i are in LDS (the caller has waited for them)
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_store(sync + 4 * (i % 3) + lw, (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        for (int i = 0; i < nk; ++i) {
-            if (i >= 2) {                                     // K-step i - 2 has landed (K-step i - 1 may still be in flight)
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                publish(i - 2);
-            }
-            if (i >= 3 && !wait_for(sync + 12 + 4 * (i % 3), (unsigned)(i - 2))) return;      // every read of K-step i - 3 has returned
-            if (!(DBG & 4) || i < 2) issue(kbeg + i, i % 3);      // (timing experiment 4: only the first two K-steps are moved)
-        }
-        if (nk >= 2) {
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            publish(nk - 2);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        publish(nk - 1);
-        return;
-    }
-    if (!active) return;
-
-    // ---- consumer: a 64 x 64 tile of the block's 128 x 128
-    const int cw = wave;                                                  // 0 .. 3
-    const int kq = lane >> 4, kp = (lane & 15) >> 2, a4 = lane & 3;
-    auto frag = [&](int stage, int op, int pl, int tt) -> bf16x8_t {
-        const int cb = 2 * (op ? wn : wm) + (tt >> 1), tt2 = tt & 1;
-        const char* base = pl_smem + stage * STAGE + ((op * 3 + pl) * 4 + cb) * 2048;
-        const int oct = (2 * tt2 + (a4 >> 1)) ^ ((kq & 1) << 1);
-        const char* q0 = base + (8 * kq + kp) * 64 + oct * 16 + (a4 & 1) * 8;
-        PlaneFrag f;
-        f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0));
-        f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_g __attribute__((address_space(3)))*)(q0 + 4 * 64));
-        return __builtin_bit_cast(bf16x8_t, f);
-    };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool rider = p.colsum != nullptr && n0 == 0 && wn == 0;        // wave-uniform
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t ones;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) ones[k] = (__bf16)1.0f;
-
-    bf16x8_t nx[5];                                                      // the first ten reads of the NEXT K-step: fa[2][0..3], fb[.][0] of tile 0
-    if (!wait_for(sync + 0, 1u)) return;
-    if constexpr (!(DBG & 2)) {
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) nx[tt] = frag(0, 0, 2, tt);
-        nx[4] = frag(0, 1, 0, 0);
-    }
-    int cur = 0;
-    for (int i = 0; i < nk; ++i) {
-        const int nxt = cur == 2 ? 0 : cur + 1;
-        bf16x8_t fa[3][4], fb[2][3];
-        unsigned snap = 0;
-        if constexpr (!(DBG & 2)) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) fa[2][tt] = nx[tt];
-            fb[0][0] = nx[4];
-#define PLANE_LOADA(PL) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) fa[PL][tt] = frag(cur, 0, PL, tt);
-            PLANE_LOADA(0) fb[0][2] = frag(cur, 1, 2, 0);
-            PLANE_LOADA(1) fb[0][1] = frag(cur, 1, 1, 0);
-#undef PLANE_LOADA
-#define PLANE_S3(PA, PB, J, B_)                                                                                  \
-            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                     \
-                acc[ii][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][ii], fb[B_][PB], acc[ii][J], 0, 0, 0);
-#define PLANE_TILE(J, B_) PLANE_S3(2, 0, J, B_) PLANE_S3(0, 2, J, B_) PLANE_S3(1, 1, J, B_) PLANE_S3(0, 1, J, B_) PLANE_S3(1, 0, J, B_) PLANE_S3(0, 0, J, B_)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int b = j & 1;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) fb[b ^ 1][pl] = frag(cur, 1, pl, j + 1);
-                // (a look at the next stage's `ready` words a tile and a half ahead of the boundary: there the answer is in a register)
-                if (j == 1) snap = __hip_atomic_load(sync + 4 * nxt + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if constexpr ((DBG & 1) != 0) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) { acc[pl][j][0] += (float)fa[pl][j][0]; acc[pl][j][1] += (float)fb[b][pl][0]; }
-                } else {
-                    if (j == 0) { PLANE_TILE(0, 0) } else if (j == 1) { PLANE_TILE(1, 1) } else { PLANE_TILE(2, 0) }
-                }
-            }
-            if constexpr ((DBG & 1) == 0) {
-                // asked of the scheduler for this block (38 reads, 72 products): tile 0's first product has its operands (read in
-                // front of the previous K-step's last tile); its other 20 reads under its first 8 products; then the 6 reads of the
-                // next tile under the first 12-18 products of a tile
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-                for (int k = 0; k < 7; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);      // (the last read 12 products ahead of the boundary's wait)
-            }
-        }
-        // ---- the boundary: every read of this K-step has returned -> the stage is free; the next stage ready -> its first reads
-        // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping has to know that nothing is outstanding
-        // here, or it drains the NEXT K-step's first reads in front of this K-step's last products; 0xc07f = lgkmcnt(0) alone)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_store(sync + 12 + 4 * cur + cw, (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (i + 1 < nk) {
-            if (!__all((int)(snap - (unsigned)(i + 2)) >= 0) && !wait_for(sync + 4 * nxt, (unsigned)(i + 2))) return;
-            asm volatile("" ::: "memory");
-            if constexpr (!(DBG & 2)) {
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) nx[tt] = frag(nxt, 0, 2, tt);
-                nx[4] = frag(nxt, 1, 0, 0);
-            }
-        }
-        if constexpr ((DBG & 3) == 0) {
-            PLANE_TILE(3, 1)
-            if (rider) {
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl)       // lo, mid, hi: small pieces first
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-                        accb[ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pl][ii], ones, accb[ii], 0, 0, 0);
-            }
-        } else if constexpr ((DBG & 2) == 0) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) { acc[pl][3][0] += (float)fa[pl][3][0]; acc[pl][3][1] += (float)fb[1][pl][0]; }
-        }
-#undef PLANE_TILE
-#undef PLANE_S3
-        cur = nxt;
-    }
-    if (rider && (lane & 15) == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + r, accb[i][r]);
-    }
-    // D[m = 4 (lane >> 4) + r][n = lane & 15] of tile (i, j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 64 * wn + 16 * j + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + r;
-                float* c = p.C + (long)m * g.ldc + n;
-                if (g.z > 1) atomicAdd(c, acc[i][j][r]);
-                else *c += acc[i][j][r];
-            }
-        }
-}
 }  // namespace
 
 // dW_i[M, N] += dG_i^T . h_i over the time steps [t, t + nT) of each problem, operands = the sweeps' three-plane copies (all
@@ -1913,28 +1486,15 @@ int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* 
     const dim3 grid(ceil_div(N, 128), M / 128, n * g.z);
     const size_t lds = 3 * 24 * 2048;
 #ifdef ARCVAE_PLANE_CLOCK
-    static unsigned long long* clk_buf = nullptr;
+    // (diagnostic build only: a buffer per call, synchronous -- no host state kept between calls)
+    unsigned long long* clk_buf = nullptr;
     const size_t clk_n = 2 * (size_t)grid.x * grid.y * grid.z;
-    if (!clk_buf) (void)hipMalloc((void**)&clk_buf, 2 * 65536 * sizeof(unsigned long long));
-    g.clk = clk_n <= 2 * 65536 ? clk_buf : nullptr;
+    if (arcvae_env_int("ARCVAE_PLANE_CLOCK_PRINT", 0)) (void)hipMalloc((void**)&clk_buf, clk_n * sizeof(unsigned long long));
+    g.clk = clk_buf;
 #endif
-    // (> 64 KB of dynamic LDS has to be allowed per kernel; set on every call: idempotent, no host state kept)
 #define PLANE_LAUNCH(D)                                                                                              \
-    { if (form == 0) {                                                                                               \
-        (void)hipFuncSetAttribute((const void*)wgrad_planes_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(wgrad_planes_kernel<D>, grid, dim3(512), lds, stream, g);                                \
-      } else if (form == 3) {                                                                                        \
-        (void)hipFuncSetAttribute((const void*)wgrad_planes_ring_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 128); \
-        hipLaunchKernelGGL(wgrad_planes_ring_kernel<D>, grid, dim3(512), lds + 128, stream, g);                     \
-      } else if (form == 1) {                                                                                        \
-        (void)hipFuncSetAttribute((const void*)wgrad_planes2_kernel<4, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((wgrad_planes2_kernel<4, D>), grid, dim3(768), lds, stream, g);                          \
-      } else {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)wgrad_planes2_kernel<8, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((wgrad_planes2_kernel<8, D>), grid, dim3(1024), lds, stream, g);                         \
-      } }
-    // ARCVAE_PLANE_FORM: 0 one consuming wave per SIMD + 4 loader waves (round 3), 1 two consuming waves per SIMD + 4 loaders, 2 + 8 loaders
-    static const int form = arcvae_env_int("ARCVAE_PLANE_FORM", 0);
+    { (void)hipFuncSetAttribute((const void*)wgrad_planes_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL(wgrad_planes_kernel<D>, grid, dim3(512), lds, stream, g); }
     switch (arcvae_env_int("ARCVAE_PLANE_DEBUG", 0)) {      // (timing experiments; results are wrong for anything but 0)
         case 1: PLANE_LAUNCH(1) break;
         case 2: PLANE_LAUNCH(2) break;
@@ -1945,15 +1505,19 @@ int arcvae_wgrad_planes_group(int n, int M, int N, int rows, const void* const* 
     }
 #undef PLANE_LAUNCH
 #ifdef ARCVAE_PLANE_CLOCK
-    if (g.clk && arcvae_env_int("ARCVAE_PLANE_CLOCK_PRINT", 0)) {       // in-kernel clock = shader cycles / (100 MHz ticks) x 100 MHz, median over blocks
+    if (clk_buf) {       // in-kernel clock = shader cycles / (100 MHz ticks) x 100 MHz, over the blocks of this call
         (void)hipStreamSynchronize(stream);
-        static unsigned long long host[2 * 65536];
-        (void)hipMemcpy(host, clk_buf, clk_n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        double ghz[65536]; int nb = 0;
-        for (size_t b = 0; b < clk_n / 2; ++b) if (host[2 * b + 1] > 0) ghz[nb++] = (double)host[2 * b] / (double)host[2 * b + 1] * 0.1;
-        std::sort(ghz, ghz + nb);
-        if (nb) fprintf(stderr, "[plane clock] blocks %d: in-kernel clock min %.3f median %.3f max %.3f GHz; K loop median %.1f us\n", nb,
-                        ghz[0], ghz[nb / 2], ghz[nb - 1], (double)host[2 * (clk_n / 4) + 1] * 0.01);
+        std::vector<unsigned long long> host(clk_n);
+        (void)hipMemcpy(host.data(), clk_buf, clk_n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(clk_buf);
+        std::vector<double> ghz, us;
+        for (size_t b = 0; b < clk_n / 2; ++b)
+            if (host[2 * b + 1] > 0) { ghz.push_back((double)host[2 * b] / (double)host[2 * b + 1] * 0.1); us.push_back((double)host[2 * b + 1] * 0.01); }
+        std::sort(ghz.begin(), ghz.end());
+        std::sort(us.begin(), us.end());
+        if (!ghz.empty())
+            fprintf(stderr, "[plane clock] blocks %zu: in-kernel clock min %.3f median %.3f max %.3f GHz; K loop median %.1f us\n", ghz.size(),
+                    ghz.front(), ghz[ghz.size() / 2], ghz.back(), us[us.size() / 2]);
     }
 #endif
     return arcvae_launch_status();
