@@ -365,14 +365,17 @@ struct TileFragS {
 #ifndef ARCVAE_S3_SADDR
 #define ARCVAE_S3_SADDR 1
 #endif
+// Which ring the three-piece contractions run on: 0 the generic NS-stage ring, 1 the branch-free two-stage ring, 2 that ring with
+// its stages pinned (tile_contract_s2<.., PIN>: counted vmcnt(24) waits; round 4: 70.0 -> 68.8 us per BPTT tile launch at configs[2],
+// 2048 rows 16.17 -> 15.5 ms -- small, because the contraction is bound by what an XCD's L2 delivers to a CU, ~70 GB/s, not by latency)
 #ifndef ARCVAE_S3_RING2_FWD
-#define ARCVAE_S3_RING2_FWD 0
+#define ARCVAE_S3_RING2_FWD 2
 #endif
 #ifndef ARCVAE_S3_RING2_BWD
 #define ARCVAE_S3_RING2_BWD 0
 #endif
 #ifndef ARCVAE_S3_RING2_KS
-#define ARCVAE_S3_RING2_KS 0
+#define ARCVAE_S3_RING2_KS 2
 #endif
 template <int MT, int NT>
 __device__ __forceinline__ void tile_load_s(TileFragS<MT, NT>& f, const __bf16* __restrict__ At, long planeA, const int* arow,
@@ -445,21 +448,34 @@ __device__ __forceinline__ void tile_mfma_s(const TileFragS<MT, NT>& f, f32x4 (&
     TILE_S3(0, 2) TILE_S3(2, 0) TILE_S3(1, 1) TILE_S3(0, 1) TILE_S3(1, 0) TILE_S3(0, 0)
 #undef TILE_S3
 }
-template <int MT, int NT>
+// PIN: a stage's loads and a stage's products stay whole and in program order (scheduling barriers between them) -- the loads of
+// chunk k + 1 are then ALL issued in front of the products of chunk k, whose wait is a counted vmcnt(24).  Left to itself the
+// compiler interleaves every load just in front of its use (fewer registers, no prefetch distance); the generic ring's
+// `if (kn < nch)` makes its wait-count bookkeeping assume the branch not taken, i.e. drain the loads it has just issued.
+template <int MT, int NT, bool PIN = false>
 __device__ __forceinline__ void tile_contract_s2(f32x4 (&acc)[MT][NT], const __bf16* __restrict__ At, long planeA,
                                                  const int* arow, int RA, const __bf16* __restrict__ Wt, long planeW,
                                                  const int* wrow, int RW, int nch, int q8) {
     TileFragS<MT, NT> f0, f1;
+#define S2_PIN() do { if constexpr (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
     tile_load_s<MT, NT>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, 0, q8);
     for (int kc = 0; kc < nch - 2; kc += 2) {
+        S2_PIN();
         tile_load_s<MT, NT>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 1, q8);
+        S2_PIN();
         tile_mfma_s<MT, NT>(f0, acc);
+        S2_PIN();
         tile_load_s<MT, NT>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 2, q8);
+        S2_PIN();
         tile_mfma_s<MT, NT>(f1, acc);
     }
+    S2_PIN();
     tile_load_s<MT, NT>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, nch - 1, q8);
+    S2_PIN();
     tile_mfma_s<MT, NT>(f0, acc);
+    S2_PIN();
     tile_mfma_s<MT, NT>(f1, acc);
+#undef S2_PIN
 }
 
 // Blocks are dealt to the XCDs round-robin by linear id, so the plain (x, y, job) order hands every XCD a slice of EVERY job:
@@ -520,9 +536,9 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
         const int q8 = (lane >> 4) * 8;
         const long pA = (long)B * H, pW = (long)G * H;
         if constexpr (NSS == 2 && ARCVAE_S3_RING2_FWD) {
-            if (j.xin) tile_contract_s2<MT, NT>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
+            if (j.xin) tile_contract_s2<MT, NT, ARCVAE_S3_RING2_FWD == 2>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
                                                 reinterpret_cast<const __bf16*>(j.Wx), pW, wrow, G, H >> 5, q8);
-            if (j.hprev) tile_contract_s2<MT, NT>(acc, reinterpret_cast<const __bf16*>(j.hprev), pA, arow, B,
+            if (j.hprev) tile_contract_s2<MT, NT, ARCVAE_S3_RING2_FWD == 2>(acc, reinterpret_cast<const __bf16*>(j.hprev), pA, arow, B,
                                                   reinterpret_cast<const __bf16*>(j.Wh), pW, wrow, G, H >> 5, q8);
         } else {
         if (j.xin) tile_contract_s<MT, NT, NSS>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
@@ -989,7 +1005,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_tile_ks3_kernel(BwdArgs a) {
         if constexpr (P == 1) {
             tile_contract_b<4, 4, 4>(acc, At, arow, B, Wt, wrow, H, nq, (lane >> 4) * 8);
         } else {
-#if ARCVAE_S3_RING2_KS
+#if ARCVAE_S3_RING2_KS == 2
+        tile_contract_s2<4, 4, true>(acc, At, (long)B * G, arow, B, Wt, (long)H * G, wrow, H, nq, (lane >> 4) * 8);
+#elif ARCVAE_S3_RING2_KS
         tile_contract_s2<4, 4>(acc, At, (long)B * G, arow, B, Wt, (long)H * G, wrow, H, nq, (lane >> 4) * 8);
 #else
         tile_contract_s<4, 4, 2>(acc, At, (long)B * G, arow, B, Wt, (long)H * G, wrow, H, nq, (lane >> 4) * 8);

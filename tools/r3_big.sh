@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=gpurun_out/r3_big_$TAG
 mkdir -p $OUT
 for cfg in "" "$@"; do
-  name=$(echo "${cfg:-auto}" | tr ' =' '__')
+  name=$(echo "${cfg:-auto}" | tr ' =/' '___')
   for shape in "--config big" "--batch-per-gpu 2048"; do
     if [ -n "$R3_ONLY" ] && [ "$shape" != "$R3_ONLY" ]; then continue; fi
     sn=$(echo "$shape" | tr ' -' '__')
