@@ -377,7 +377,10 @@ struct TileFragS {
 #ifndef ARCVAE_S3_RING2_KS
 #define ARCVAE_S3_RING2_KS 2
 #endif
-template <int MT, int NT>
+#ifndef ARCVAE_DBG_SKIP_A
+#define ARCVAE_DBG_SKIP_A 0      // timing experiment (variant builds only): waves 1-3 of a forward tile block do not load the A operand
+#endif
+template <int MT, int NT, bool SKIPA = false>
 __device__ __forceinline__ void tile_load_s(TileFragS<MT, NT>& f, const __bf16* __restrict__ At, long planeA, const int* arow,
                                             int RA, const __bf16* __restrict__ Wt, long planeW, const int* wrow, int RW, int kc,
                                             int q8) {
@@ -399,9 +402,14 @@ __device__ __forceinline__ void tile_load_s(TileFragS<MT, NT>& f, const __bf16* 
     for (int p = 0; p < 3; ++p) {
         const __bf16* ab = At + p * planeA + (long)kc * RA * 32;
         const __bf16* wb = Wt + p * planeW + (long)kc * RW * 32;
+        if (!SKIPA || threadIdx.x < 64) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            f.a[p][m] = *reinterpret_cast<const u32x4_l*>(ab + (unsigned)(arow[m] * 32 + q8));
+            for (int m = 0; m < MT; ++m)
+                f.a[p][m] = *reinterpret_cast<const u32x4_l*>(ab + (unsigned)(arow[m] * 32 + q8));
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) f.a[p][m] = u32x4_l{0u, 0u, 0u, 0u};
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n)
             f.w[p][n] = *reinterpret_cast<const u32x4_l*>(wb + (unsigned)(wrow[n] * 32 + q8));
@@ -452,25 +460,25 @@ __device__ __forceinline__ void tile_mfma_s(const TileFragS<MT, NT>& f, f32x4 (&
 // chunk k + 1 are then ALL issued in front of the products of chunk k, whose wait is a counted vmcnt(24).  Left to itself the
 // compiler interleaves every load just in front of its use (fewer registers, no prefetch distance); the generic ring's
 // `if (kn < nch)` makes its wait-count bookkeeping assume the branch not taken, i.e. drain the loads it has just issued.
-template <int MT, int NT, bool PIN = false>
+template <int MT, int NT, bool PIN = false, bool SKIPA = false>
 __device__ __forceinline__ void tile_contract_s2(f32x4 (&acc)[MT][NT], const __bf16* __restrict__ At, long planeA,
                                                  const int* arow, int RA, const __bf16* __restrict__ Wt, long planeW,
                                                  const int* wrow, int RW, int nch, int q8) {
     TileFragS<MT, NT> f0, f1;
 #define S2_PIN() do { if constexpr (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
-    tile_load_s<MT, NT>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, 0, q8);
+    tile_load_s<MT, NT, SKIPA>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, 0, q8);
     for (int kc = 0; kc < nch - 2; kc += 2) {
         S2_PIN();
-        tile_load_s<MT, NT>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 1, q8);
+        tile_load_s<MT, NT, SKIPA>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 1, q8);
         S2_PIN();
         tile_mfma_s<MT, NT>(f0, acc);
         S2_PIN();
-        tile_load_s<MT, NT>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 2, q8);
+        tile_load_s<MT, NT, SKIPA>(f0, At, planeA, arow, RA, Wt, planeW, wrow, RW, kc + 2, q8);
         S2_PIN();
         tile_mfma_s<MT, NT>(f1, acc);
     }
     S2_PIN();
-    tile_load_s<MT, NT>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, nch - 1, q8);
+    tile_load_s<MT, NT, SKIPA>(f1, At, planeA, arow, RA, Wt, planeW, wrow, RW, nch - 1, q8);
     S2_PIN();
     tile_mfma_s<MT, NT>(f0, acc);
     S2_PIN();
@@ -536,9 +544,9 @@ __global__ __launch_bounds__(256, (P == 2 ? ARCVAE_S3_LBF : 1)) void lstm_fwd_ti
         const int q8 = (lane >> 4) * 8;
         const long pA = (long)B * H, pW = (long)G * H;
         if constexpr (NSS == 2 && ARCVAE_S3_RING2_FWD) {
-            if (j.xin) tile_contract_s2<MT, NT, ARCVAE_S3_RING2_FWD == 2>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
+            if (j.xin) tile_contract_s2<MT, NT, ARCVAE_S3_RING2_FWD == 2, (ARCVAE_DBG_SKIP_A != 0)>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
                                                 reinterpret_cast<const __bf16*>(j.Wx), pW, wrow, G, H >> 5, q8);
-            if (j.hprev) tile_contract_s2<MT, NT, ARCVAE_S3_RING2_FWD == 2>(acc, reinterpret_cast<const __bf16*>(j.hprev), pA, arow, B,
+            if (j.hprev) tile_contract_s2<MT, NT, ARCVAE_S3_RING2_FWD == 2, (ARCVAE_DBG_SKIP_A != 0)>(acc, reinterpret_cast<const __bf16*>(j.hprev), pA, arow, B,
                                                   reinterpret_cast<const __bf16*>(j.Wh), pW, wrow, G, H >> 5, q8);
         } else {
         if (j.xin) tile_contract_s<MT, NT, NSS>(acc, reinterpret_cast<const __bf16*>(j.xin), pA, arow, B,
