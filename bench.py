@@ -734,6 +734,9 @@ def main(argv=None):
                 if prec == "fp32":
                     legs[prec]["frac_of_f32_mfma_peak"] = sq * f_seq2 / 1e12 / PEAK_F32_MFMA_TFLOPS
                     legs[prec]["executed_frac_of_f32_mfma_peak"] = legs[prec]["step_tflops_executed"] / PEAK_F32_MFMA_TFLOPS
+                    legs[prec]["frac_note"] = ("frac_of_f32_mfma_peak is SURVEY 8(d)'s stated ratio (algorithmic f32 FLOP / 157.3 TFLOP/s) and "
+                                               "can exceed 1: the three-piece kernels issue bf16 products, not f32 MFMAs -- read the two "
+                                               "executed_frac_of_* fields against the pipe in use")
                     # every large contraction of this leg runs in the three-piece form (sweeps, plane GEMMs, dense decoder stack):
                     # the bf16 products issued per second against the pipe they issue on
                     legs[prec]["executed_frac_of_bf16_pipe"] = 6.0 * legs[prec]["step_tflops_executed"] / 2500.0
