@@ -57,7 +57,12 @@ def test_committed_bench_line_has_every_contract_field():
     assert b["dtype"] == "bf16" and b["ms_per_step"] > 0 and "tolerance" in b and "NOT" in b["tolerance"]
     o = d["other_configs"]["configs[2]"]
     assert o["fp32"]["dtype"] == "f32" and o["bf16"]["dtype"] == "bf16"
-    assert 0.0 < o["fp32"]["frac_of_f32_mfma_peak"] < 1.0 and 0.0 < o["bf16"]["frac_of_bf16_mfma_peak"] < 1.0
+    # (SURVEY 8(d)'s ratio for configs[2] is algorithmic f32 FLOP over the f32 MFMA peak; the three-piece kernels issue bf16 products,
+    # so since round 4 it can pass 1 -- then the line must say so, and the fraction of the pipe in use must be a fraction)
+    assert 0.0 < o["fp32"]["frac_of_f32_mfma_peak"] < 1.5 and 0.0 < o["bf16"]["frac_of_bf16_mfma_peak"] < 1.0
+    assert 0.0 < o["fp32"]["executed_frac_of_bf16_pipe"] < 1.0
+    if o["fp32"]["frac_of_f32_mfma_peak"] >= 1.0:
+        assert "frac_note" in o["fp32"]
 
 
 def test_bench_source_names_the_contract_fields():
