@@ -66,6 +66,12 @@ extern "C" {
                                    * bit 1: throughput mode for the persistent sweeps -- the 4x4 MFMA blocks (H 256, B <= 64
                                    * forward, B <= 128 BPTT) on v_mfma_f32_4x4x4_16b_bf16, weights and h / dG rounded to bf16
                                    * on their way into the instruction */
+#define ARCVAE_RS_HALF 16         /* arcvae_enc_lstm_backward_persistent_rs flags bit 4: the half-batch form (129 <= B <= 256 where
+                                   * arcvae_enc_lstm_bwd_rs_halves says so): this call sweeps rows 32 x + 16 half + [0, 16) of XCD x
+                                   * only -- half = 0, or 1 with ARCVAE_RS_HALF1 -- and a chunk of the BPTT is TWO calls, one per
+                                   * half, on the same stream with the same sync_ws / part_ws (a 16-row tick costs 4.0 us, the 32-row
+                                   * block's 9.7) */
+#define ARCVAE_RS_HALF1 32        /* ... flags bit 5: the second half */
 #define ARCVAE_DEC_SPLIT3 512     /* arcvae_dec_forward_dense `mode` bit 9 / arcvae_dec_backward_dense `flags` bit 9: the B*V-row
                                    * products with ARCVAE_GEMM_SPLIT3 (fp32-class accuracy, less matrix-pipe time beside a sweep) */
 #define ARCVAE_DEC_NO_GPRE 1024   /* arcvae_dec_forward_dense `mode` bit 10: forward only (sampler, loss-only forward) -- `gpre` is not
@@ -197,6 +203,8 @@ int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L);
 /* Floats of part_ws that sweep uses for this shape under the current knobs (0 where it does not run): pass the capacity the
  * caller allocated as part_ws_floats -- a call that would need more returns ARCVAE_ERR_ARG. */
 long arcvae_enc_lstm_bwd_rs_part_floats(int B, int T, int H, int L);
+/* 1 where that sweep runs as two half-batch sweeps per chunk (ARCVAE_RS_HALVES=1, 129 <= B <= 256): see ARCVAE_RS_HALF. */
+int arcvae_enc_lstm_bwd_rs_halves(int B, int T, int H, int L);
 /* 2 where the persistent sweeps run in their TWO-GROUP form (H = 256, L <= 2, 129 <= B <= 256: the 256-row shard of
  * BASELINE.json configs[3]), else 1.  Two groups: 512 blocks, two per CU; every XCD's 17..32 rows are two independent
  * recurrences of up to 16 rows with their own flag lines, and a CU's two blocks serve different groups, so that one group's
@@ -209,7 +217,8 @@ int arcvae_enc_lstm_backward_persistent_rs(const float* const* Wx, const float* 
                                            float* dxs, float* part_ws, long part_ws_floats, unsigned* sync_ws,
                                            unsigned* start_signal, int B, int T, int H, int L, int s_begin, int s_end, int chunk_index,
                                            int flags /* bit 0: sync_ws was re-armed ahead of the step (arcvae_enc_prologue with
-                                           n_sync >= 848); bit 1: ARCVAE_PERSIST_BF16 */, unsigned long long* trace,
+                                           n_sync >= 848); bit 1: ARCVAE_PERSIST_BF16; bits 4, 5: ARCVAE_RS_HALF, ARCVAE_RS_HALF1 */,
+                                           unsigned long long* trace,
                                            arcvae_stream_t stream);
 /* The reduce-scatter sweep with the stack's weight gradients formed INSIDE the kernel: replaces
  * arcvae_enc_lstm_backward_persistent_rs + the per-layer GEMMs / bias sums / token segment-sum of arcvae_enc_lstm_wgrad

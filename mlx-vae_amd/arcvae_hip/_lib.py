@@ -23,6 +23,7 @@ GEMM_SPLIT3 = 512    # three bf16 pieces per operand, six products: fp32-class a
 LSTM_RETILE = 1      # arcvae_enc_lstm_backward flags
 LSTM_BF16 = 2        # arcvae_enc_lstm_forward / _backward flags: throughput mode (tiled regime)
 LSTM_SPLIT3 = 4      # same places: three bf16 pieces per operand, six products -- a parity path (tiled regime)
+RS_HALF, RS_HALF1 = 16, 32   # arcvae_enc_lstm_backward_persistent_rs flags: the half-batch form (129..256 rows as two 16-row-per-XCD sweeps)
 PERSIST_BF16 = 2     # arcvae_enc_lstm_forward_persistent / _backward_persistent_rs flags: throughput mode (4x4x4 bf16 blocks)
 DEC_BF16 = 256       # arcvae_dec_forward_dense mode bit / arcvae_dec_backward_dense flags bit
 DEC_SPLIT3 = 512     # same places: three-piece (fp32-class) products
@@ -60,6 +61,7 @@ SIGNATURES = {
     "arcvae_enc_lstm_bwd_persistent_ok": [_i, _i, _i, _i],
     "arcvae_enc_lstm_backward_persistent": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "arcvae_enc_lstm_bwd_rs_ok": [_i, _i, _i, _i],
+    "arcvae_enc_lstm_bwd_rs_halves": [_i, _i, _i, _i],
     "arcvae_enc_lstm_persist_groups": [_i, _i, _i],
     "arcvae_enc_lstm_bwd_rs_part_floats": [_i, _i, _i, _i],
     "arcvae_enc_lstm_backward_persistent_rs": [_pp, _pp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],

@@ -589,10 +589,14 @@ class EncoderBackwardPlan:
         if self.persistent:
             # latency regime, default shape: persistent BPTT sweep in its reduce-scatter form, one launch per chunk
             # (csrc/lstm.hip: lstm_bwd_persist_rs_kernel)
-            call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
-                 ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), C.c_long(ws.ppart.numel()), ptr(ws.psync), sig,
-                 ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0) | rearmed,
-                 ptr(ws.trace_bwd), stream_ptr())
+            # (half-batch form, round 4: 129..256 rows as two sweeps of 16 rows per XCD per chunk, one behind the other)
+            halves = _lib.load().arcvae_enc_lstm_bwd_rs_halves(ws.B, ws.T, d.H, d.L) == 1
+            for hf in ((_lib.RS_HALF, _lib.RS_HALF | _lib.RS_HALF1) if halves else (0,)):
+                call("arcvae_enc_lstm_backward_persistent_rs", self._wx[0], self._wh[0], ptr(ws.cseq), ptr(ws.gseq),
+                     ptr(ws.dcomb), 2 * d.H, ptr(ws.dG), ptr(ws.dcs), ptr(ws.dxs), ptr(ws.ppart), C.c_long(ws.ppart.numel()), ptr(ws.psync),
+                     sig if not (hf & _lib.RS_HALF1) else C.c_void_p(0),
+                     ws.B, ws.T, d.H, d.L, s0, s1, chunk_index, (_lib.PERSIST_BF16 if ws.bf16_parts & 1 else 0) | rearmed | hf,
+                     ptr(ws.trace_bwd) if not (hf & _lib.RS_HALF1) else C.c_void_p(0), stream_ptr())
             return
         if _lib.load().arcvae_enc_lstm_bwd_persistent_ok(ws.B, ws.T, d.H, d.L) == 1:
             # latency regime: one persistent launch per chunk (csrc/lstm.hip: lstm_bwd_persist_kernel)

@@ -2007,6 +2007,8 @@ struct PersistBwdArgs {
     unsigned long long* trace;
     int B, T, H, RX, RS, ld_dh_top, s_begin, s_end, cnt_off, prio;
     int stagger;              // two-group form: group 1 starts this many 10 ns units late (ps_stagger)
+    int row_base, row_xs;     // reduce-scatter sweep: XCD x works on rows row_base + x * row_xs + [0, RX) (default 0, RX; the
+                              // half-batch form of round 4: row_xs = 32, row_base = 16 * half, RX = 16)
 };
 
 template <int NT, int LL, int RT>   // RT = 16-row MFMA tiles per XCD (rows per XCD RX <= 16 * RT)
@@ -2367,7 +2369,7 @@ __global__ __launch_bounds__(256, NG) void lstm_bwd_persist_rs_kernel(PersistRsA
     if constexpr (FW)
         for (int i = tid; i < ar.V * 33; i += 256) dtl[i] = 0.f;   // row stride 33: rows of different tokens on different banks
     __syncthreads();
-    const int row0 = xcc * a.RX + 16 * (int)grp;
+    const int row0 = a.row_base + (int)xcc * a.row_xs + 16 * (int)grp;
     const long sH = (long)B * H, sG = (long)B * G, lH = (long)T * sH, lG = (long)T * sG;
     // the gate-gradient image of row `rw` of 8-row half g, layer l: one 16-row image (R16) or an image per half
     auto dgl_row = [&](int g, int l, int rw) -> float* {
@@ -3117,6 +3119,7 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
     a.wT = wT; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
     a.sync = sync_ws + PS_BWD; a.err = sync_ws + PS_ERR; a.start_signal = start_signal; a.trace = trace;
     a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
+    a.row_base = 0; a.row_xs = a.RX;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
     a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);   // chunk 0: words 256..263, then 272..
     a.flags = a.sync + PS_FLAGS; a.cnt = a.sync + PS_CNT + a.cnt_off; a.cucnt = nullptr; a.stagger = 0;
@@ -3133,10 +3136,17 @@ extern "C" int arcvae_enc_lstm_backward_persistent(const float* cseq, const floa
 
 
 // 1 if arcvae_enc_lstm_backward_persistent_rs supports the shape (and ARCVAE_PERSIST != 0).
+// 1 if the reduce-scatter BPTT of this shape runs as two half-batch sweeps (ARCVAE_RS_HALVES, 129..256 rows; see launch_bwd_rs):
+// the caller then makes two calls per chunk, flags ARCVAE_RS_HALF and ARCVAE_RS_HALF | ARCVAE_RS_HALF1.
+extern "C" int arcvae_enc_lstm_bwd_rs_halves(int B, int T, int H, int L) {
+    return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && arcvae_env_int("ARCVAE_RS_HALVES", 0) != 0 && H == 256 && L >= 1 && L <= 2 &&
+            B > 128 && B <= 256 && T >= 1 && !persist_two_groups(B, H, L, 2)) ? 1 : 0;
+}
 extern "C" int arcvae_enc_lstm_bwd_rs_ok(int B, int T, int H, int L) {
     // ARCVAE_RS_MAX_B
     return (arcvae_env_int("ARCVAE_PERSIST", 1) != 0 && H == 256 && L >= 1 && L <= 2 && B >= 1 &&
-            (B <= arcvae_env_int("ARCVAE_RS_MAX_B", 128) || persist_two_groups(B, H, L, 2)) && B <= 256 && T >= 1) ? 1 : 0;
+            (B <= arcvae_env_int("ARCVAE_RS_MAX_B", 128) || persist_two_groups(B, H, L, 2) ||
+             arcvae_enc_lstm_bwd_rs_halves(B, T, H, L) == 1) && B <= 256 && T >= 1) ? 1 : 0;
 }
 
 // 2 if the persistent sweeps of this shape run in their two-group form (two blocks per CU, the XCD's 17..32 rows as two
@@ -3175,25 +3185,33 @@ int launch_bwd_rs(const float* const* Wx, const float* const* Wh, const float* c
     if (H != 256 || L < 1 || L > 2 || B < 1 || B > 256 || T < 1 || ld_dh_top < H) return ARCVAE_ERR_ARG;
     if (arcvae_env_int("ARCVAE_PERSIST", 1) == 0) return ARCVAE_ERR_ARG;
     if (part_ws_floats < bwd_rs_part_floats(B, H, L)) return ARCVAE_ERR_ARG;   // (the form is re-decided at every call: refuse, never overrun)
-    const int rows_x = ceil_div(B, 8);                                  // rows per XCD
+    // Half-batch form (round 4; flags bit 4, bit 5 = which half): 129..256 rows as TWO sweeps of 16 rows per XCD -- this call walks
+    // rows 32 x + 16 half + [0, 16) of XCD x, the other half is a second call behind it on the same stream (its sync words: the
+    // two-group BPTT's, unused in this form).  A 16-row tick is 4.0 us against 9.7 for 32 rows in one block.
+    const bool halves = (flags & ARCVAE_RS_HALF) != 0;
+    const int half = (flags & ARCVAE_RS_HALF1) ? 1 : 0;
+    if (halves && (fused || B <= 128 || (flags & ARCVAE_PERSIST_BF16))) return ARCVAE_ERR_ARG;
+    const int rows_x = halves ? 16 : ceil_div(B, 8);                    // rows per XCD (of this call)
     // two-group form (17..32 rows per XCD): two blocks per CU, each group an independent 16-row recurrence (R16 tile form)
-    const bool two = !fused && !(flags & ARCVAE_PERSIST_BF16) && persist_two_groups(B, H, L, 2);
+    const bool two = !halves && !fused && !(flags & ARCVAE_PERSIST_BF16) && persist_two_groups(B, H, L, 2);
     const int rgn = two ? 2 : (rows_x <= 8 ? 1 : (rows_x <= 16 ? 2 : 4));   // groups of 8 rows a tick walks (per block)
     if (fused && rgn != 1) return ARCVAE_ERR_ARG;
     const int S = T + 2 * (L - 1);
     if (s_begin < 0 || s_end > S || s_begin >= s_end) return ARCVAE_ERR_ARG;
     if (chunk_index < 0 || chunk_index >= 8 || (chunk_index == 0) != (s_begin == 0)) return ARCVAE_ERR_ARG;
+    const int bwd_base = (halves && half) ? PS2_BWD_FLAGS : PS_BWD;       // where this sweep's flags / role counters live
     if (chunk_index == 0 && !(flags & 1)) {   // flags bit 0: the words were zeroed ahead of the step (arcvae_enc_prologue)
         int rc = two ? arcvae_zero(reinterpret_cast<float*>(sync_ws + PS2_BWD_FLAGS), 1, PS2_CU - PS2_BWD_FLAGS, PS2_CU - PS2_BWD_FLAGS, stream)
-                     : arcvae_zero(reinterpret_cast<float*>(sync_ws + PS_BWD), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
+                     : arcvae_zero(reinterpret_cast<float*>(sync_ws + bwd_base), 1, PS_WORDS + 64, PS_WORDS + 64, stream);
         if (rc == ARCVAE_OK) rc = arcvae_zero(reinterpret_cast<float*>(sync_ws + PS3_DONE), 1, 512, 512, stream);   // the "gathered" words
         if (rc != ARCVAE_OK) return rc;
     }
     PersistRsArgs ar;
     PersistBwdArgs& a = ar.b;
     a.wT = nullptr; a.cseq = cseq; a.gseq = gseq; a.dh_top = dh_top; a.dG = dG; a.dcs = dcs; a.dxs = dxs;
-    a.sync = sync_ws + PS_BWD; a.err = sync_ws + PS_ERR; a.start_signal = start_signal; a.trace = trace;
-    a.B = B; a.T = T; a.H = H; a.RX = ceil_div(B, 8); a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
+    a.sync = sync_ws + bwd_base; a.err = sync_ws + PS_ERR; a.start_signal = start_signal; a.trace = trace;
+    a.B = B; a.T = T; a.H = H; a.RX = rows_x; a.RS = arcvae_ring_slots(T); a.ld_dh_top = ld_dh_top;
+    a.row_base = halves ? 16 * half : 0; a.row_xs = halves ? 32 : rows_x;
     a.s_begin = s_begin; a.s_end = s_end; a.prio = arcvae_step_prio();
     a.cnt_off = chunk_index == 0 ? 0 : (PS_WORDS - PS_CNT) + 8 * (chunk_index - 1);
     a.flags = a.sync + PS_FLAGS; a.cnt = a.sync + PS_CNT + a.cnt_off; a.cucnt = nullptr; a.stagger = 0;

@@ -518,7 +518,10 @@ def test_persistent_sweeps_are_repeatable(H, L, B, T):
                                  # round 3: both sweeps in the two-group form (two blocks per CU); the one-group kernels for
                                  # up to 32 rows per XCD in the 16-row tile form and in the 4x4x1 walk
                                  {"ARCVAE_PERSIST2": "3"}, {"ARCVAE_PERSIST2": "0", "ARCVAE_RS_MAX_B": "256"},
-                                 {"ARCVAE_PERSIST2": "0", "ARCVAE_RS_MAX_B": "256", "ARCVAE_RS_R16": "0"}])
+                                 {"ARCVAE_PERSIST2": "0", "ARCVAE_RS_MAX_B": "256", "ARCVAE_RS_R16": "0"},
+                                 # round 4: the BPTT of 129..256 rows as two half-batch reduce-scatter sweeps per chunk
+                                 # (behind the two-group and behind the one-group forward)
+                                 {"ARCVAE_RS_HALVES": "1"}, {"ARCVAE_RS_HALVES": "1", "ARCVAE_PERSIST2": "0"}])
 @pytest.mark.parametrize("H,L,B,T,C", [(128, 2, 20, 9, 1), (128, 1, 33, 7, 2), (256, 2, 64, 12, 1), (384, 1, 9, 5, 1),
                                        (128, 2, 200, 6, 1), (256, 2, 250, 5, 1), (256, 2, 128, 6, 1),   # > 128 rows: two row tiles per XCD
                                        (128, 2, 3, 4, 1),                                                 # fewer rows than XCDs
@@ -535,6 +538,10 @@ def test_persistent_sweeps_and_their_fallback(env, H, L, B, T, C, monkeypatch):
     params, x, cond, eps, coins = make_case(cfg, B, T, 0.6)
     vals, grads = _oracle(cfg, params, x, cond, eps, coins)
     eng, enc, dec = build_engine(cfg, params)
+    if env.get("ARCVAE_RS_HALVES") == "1" and H == 256 and 128 < B <= 256:     # the form under test really is the one that runs
+        from arcvae_hip import _lib, engine as E
+        assert _lib.load().arcvae_enc_lstm_bwd_rs_halves(B, T, H, L) == 1
+        assert E.EncoderBackwardPlan(enc, eng.workspace(B, T), eng.d).persistent
     for rep in range(2):
         out = eng.train_step(x, cond, eps, coins, lr=2e-4, update=False, **HYPER)
     torch.cuda.synchronize()

@@ -13,7 +13,7 @@ for cfg in "RH_B=64" "RH_B=64 ARCVAE_RS_MFMA=0" "RH_B=64 ARCVAE_PERSIST_BWD=0" "
            "RH_B=288 RH_T=20 ARCVAE_STEP_TILE=4 ARCVAE_BWD_KSPLIT3=0 ARCVAE_DENSE_TILED=2" \
            "RH_B=512 RH_T=8 ARCVAE_STEP_TILE=4 ARCVAE_WGRAD_PLANES=0" \
            "RH_B=64 ARCVAE_SEAM_FUSED=1" "RH_B=37 RH_T=19 ARCVAE_SEAM_FUSED=1" "RH_B=64 ARCVAE_MERGE_FINISH=0" \
-           "RH_B=256 ARCVAE_RS_MAX_B=256 ARCVAE_WGRAD_CONVERT=1"; do
+           "RH_B=256 ARCVAE_RS_MAX_B=256 ARCVAE_WGRAD_CONVERT=1" "RH_B=256 ARCVAE_RS_HALVES=1" "RH_B=200 RH_T=17 ARCVAE_RS_HALVES=1"; do
   echo "== $cfg"
   env $cfg timeout -k 10 150 python tools/race_hunt.py $N 2>&1 | grep -v amdgpu.ids | tail -8
 done
